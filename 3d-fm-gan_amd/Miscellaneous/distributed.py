@@ -1,0 +1,154 @@
+"""One-process-per-GPU data parallelism over RCCL/xGMI (replaces the reference's nn.DataParallel wrapping,
+train_3_encoder.py:355-362, and its dormant Miscellaneous/distributed.py helpers).
+
+API kept: get_rank, synchronize, get_world_size, reduce_sum, gather_grad, all_gather, reduce_loss_dict
+(Miscellaneous/distributed.py:18-135) — same arithmetic (SUM then / world; reduce of sorted, stacked losses to
+rank 0).  Added: init_distributed() (env rendezvous; backend "nccl" is RCCL on ROCm, "gloo" on CPU),
+Replica (exposes .module like DataParallel did) and shard_range().
+
+Design for xGMI (7 point-to-point links per GPU): the forward path needs NO collective — each rank
+runs the whole (photo, render) -> image stack on its own shard of pairs.  Training all-reduces gradients in a few
+large flat buckets (default 256 MiB) instead of the reference's one all_reduce per parameter tensor
+(distributed.py:66-75): E_W_Plus alone is ~1 GB of fp32 gradients in ~300 tensors, and per-link-bound rings want
+few, large messages.
+"""
+import os
+import pickle
+
+import torch
+from torch import distributed as dist
+from torch import nn
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_distributed(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun). Returns (rank, world, device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not _active():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        kw = {'device_id': device} if use_gpu else {}
+        dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def get_rank():
+    return dist.get_rank() if _active() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if _active() else 1
+
+
+def synchronize():
+    if _active() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def shard_range(total, rank=None, world=None):
+    """Contiguous [lo, hi) slice of `total` units owned by `rank` (units = (photo, render) pairs)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_sum(tensor):
+    if not _active():
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def gather_grad(params, bucket_bytes=256 << 20):
+    """Average gradients over ranks: all_reduce(SUM) then / world (distributed.py:66-75), bucketed into flat buffers."""
+    world = get_world_size()
+    if world == 1:
+        return
+    grads = [p.grad.data for p in params if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for g in bucket:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+        bucket, size = [], 0
+
+    last_dtype = None
+    for g in grads:
+        if last_dtype is not None and g.dtype != last_dtype:
+            flush()
+        last_dtype = g.dtype
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+
+
+def all_gather(data):
+    """Gather arbitrary picklable objects from every rank (distributed.py:78-110)."""
+    world = get_world_size()
+    if world == 1:
+        return [data]
+    out = [None] * world
+    dist.all_gather_object(out, data)
+    return out
+
+
+def reduce_loss_dict(loss_dict):
+    """Mean of each scalar loss on rank 0 (distributed.py:113-135): sorted keys -> stack -> reduce(dst=0) -> / world."""
+    world = get_world_size()
+    if world < 2:
+        return loss_dict
+    with torch.no_grad():
+        keys = sorted(loss_dict.keys())
+        losses = torch.stack([loss_dict[k] for k in keys], 0)
+        dist.reduce(losses, dst=0)
+        if dist.get_rank() == 0:
+            losses /= world
+        return {k: v for k, v in zip(keys, losses)}
+
+
+class Replica(nn.Module):
+    """Per-rank stand-in for nn.DataParallel(net): callers reach the network as `.module` (train_3_encoder.py:353,
+    Util/network_util.py:317-318).  Forward is local; gradients are synchronised explicitly with gather_grad(),
+    or wrap the module in torch's DistributedDataParallel, which also exposes `.module`."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def data_parallel(module, device=None, overlap=True):
+    """DataParallel replacement: DDP (bucketed RCCL all-reduce overlapped with backward) when a process group is up
+    and the module has trainable parameters, else a plain Replica."""
+    if device is not None:
+        module = module.to(device)
+    if _active() and get_world_size() > 1 and overlap and any(p.requires_grad for p in module.parameters()):
+        ids = [device.index] if (device is not None and device.type == 'cuda') else None
+        return nn.parallel.DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=256,
+                                                   gradient_as_bucket_view=True)
+    return Replica(module)

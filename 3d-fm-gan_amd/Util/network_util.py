@@ -1,0 +1,73 @@
+"""Composition of the hot path: (photo, render) -> image  (reference: Util/network_util.py).
+
+Kept for the callers (train_3_encoder.py:460,507,574; Evaluation/visual_eval.py:116,180,296; quant_eval.py:93,162):
+Forward_Inference_3_Encoder, Build_Generator_From_Dict, Get_Network_Shape, Get_Conv_Kernel_Key.
+Image/PIL helpers of the reference file (torchvision-based) are not on the path and not provided.
+"""
+import torch
+
+from stylegan2 import Generator
+
+MODULATION_ENCODING = ['Render Image', 'Photo Image']
+CO_MODULATION_MODE = ['Multiplication', 'Concatenation', 'Tensor Transform']
+
+
+def Get_Conv_Kernel_Key(model_dict):
+    """Keys of the main-path modulated conv weights, first to last (Util/network_util.py:22-36)."""
+    return ['conv1.conv.weight'] + [k for k in model_dict.keys() if 'convs' in k and 'conv.weight' in k]
+
+
+def Get_Network_Shape(model_dict):
+    """Channel widths per synthesis layer, inferred from the conv weight shapes [1,Cout,Cin,k,k] (:39-50)."""
+    keys = Get_Conv_Kernel_Key(model_dict)
+    return [model_dict[k].shape[2] for k in keys] + [model_dict[keys[-1]].shape[1]]
+
+
+def Build_Generator_From_Dict(model_dict, size=256, latent=512, n_mlp=8):
+    """Generator whose (possibly pruned) widths are read off a state_dict, then loaded (:101-115)."""
+    generator = Generator(size, latent, n_mlp, generator_net_shape=Get_Network_Shape(model_dict))
+    generator.load_state_dict(model_dict, strict=False)
+    return generator
+
+
+def _unwrapped(net):
+    # The reference reads g_ema.module.n_latent and therefore only works on a DataParallel-wrapped generator
+    # (Util/network_util.py:317-318).  DDP and Miscellaneous.distributed.Replica also expose .module;
+    # a bare Generator is accepted too.
+    return getattr(net, 'module', net)
+
+
+def Forward_Inference_3_Encoder(p_input, r_input, E_Tsr, E_W, E_W_Plus, g_ema, tsr_encode='Photo Image',
+                                sliced_layer=None, use_tanh=False, PPL_regularize=False):
+    """One forward of the 3-encoder scheme with multiplicative co-modulation (Util/network_util.py:293-338).
+
+    tsr = E_Tsr(photo | render) [N,512,4,4];  W = E_W(render) [N,512];  W+ = E_W_Plus(photo) [N,n_latent,512];
+    latent[:, i] = W * W+[:, i] for i in sliced_layer else W;  image = g_ema(latent, external_input_tensor=tsr).
+    """
+    if tsr_encode == 'Photo Image':
+        encoded_tensor = E_Tsr(p_input)
+    elif tsr_encode == 'Render Image':
+        encoded_tensor = E_Tsr(r_input)
+    else:
+        raise ValueError(f'tsr_encode must be one of {MODULATION_ENCODING}')
+    encoded_W = E_W(r_input)
+    encoded_W_plus = E_W_Plus(p_input)
+
+    n_styles = encoded_W_plus.shape[1]
+    if sliced_layer is None:
+        sliced_layer = range(_unwrapped(g_ema).n_latent)
+    mask = torch.zeros(n_styles, dtype=torch.bool)
+    mask[[i for i in sliced_layer if i < n_styles]] = True
+    # W (.) W+ where sliced, W elsewhere — one broadcast op instead of a Python loop + stack + transpose
+    w_b = encoded_W.unsqueeze(1)
+    encoded_latent = torch.where(mask.view(1, -1, 1).to(w_b.device), w_b * encoded_W_plus, w_b.expand_as(encoded_W_plus))
+
+    g_output = g_ema(noise_z=None, latent_styles=[encoded_latent], input_is_latent=True,
+                     use_external_input_tensor=True, external_input_tensor=encoded_tensor,
+                     PPL_regularize=PPL_regularize)
+    if use_tanh:
+        if PPL_regularize:
+            g_output = (torch.tanh(g_output[0]),) + tuple(g_output[1:])
+        else:
+            g_output = torch.tanh(g_output)
+    return g_output

@@ -1,0 +1,315 @@
+// upfirdn2d for gfx950 (MI355X): upsample - FIR - downsample in one pass.
+//
+// Replaces upfirdn2d_op / upfirdn2d_kernel<> / upfirdn2d_kernel_large of the
+// reference (op/upfirdn2d_kernel.cu:49-105, 107-207, 209-369).  Same maths:
+//   out[n,oy,ox,m] = sum_{ky,kx} kflip[ky,kx] * U[n, oy*down_y + ky - pad_y0, ox*down_x + kx - pad_x0, m]
+//   U = input zero-stuffed by (up_y, up_x);  kflip[ky,kx] = kernel[kh-1-ky, kw-1-kx]
+// accumulated in tap order (ky outer, kx inner, ascending), as the reference's tile kernel does.
+//
+// Design (not a translation of the CUDA tiling):
+//  * This op is pure HBM streaming (<= 4 flop/B).  The hot configuration is the 4x4 blur after
+//    every transposed conv, [B*C, 2H+1, 2W+1] -> [B*C, 2H, 2W], rows of 2W+1 floats that are never
+//    16-byte aligned.  Path 1 ("row-march") gives each 64-lane wave a 64*VEC-column strip and
+//    marches it down TH output rows: one dword-aligned global_load_dwordx4 per lane per input row
+//    (1 KiB contiguous per wave-instruction), the 3 halo columns come from the neighbouring lane
+//    by wave shuffle, the 4-row vertical window lives in registers (rolling, statically unrolled
+//    by 4) and the 16 taps sit in SGPRs.  Every input row is read once per row-tile ((TH+3)/TH
+//    amplification, halo rows are L2/MALL hits thanks to the XCD-contiguous block order) and every
+//    output row is written once with dwordx4 stores.
+//  * Path 2 ("plane-tile") stages whole small planes (<= 65x65) in LDS with flat coalesced loads:
+//    at 4..64 px the planes are too narrow for a wave-wide strip.
+//  * Path 0 is the generic fallback (any up/down/pad/kernel/minor, f32/f64/f16).
+#include "common.h"
+
+namespace {
+
+struct UfdParams {
+  int major, in_h, in_w, minor, kh, kw;
+  int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+  int out_h, out_w;
+};
+
+// ---------------------------------------------------------------- path 0: generic
+template <typename T>
+__global__ __launch_bounds__(256) void ufd_generic(const T* __restrict__ in, const T* __restrict__ kern,
+                                                   T* __restrict__ out, const UfdParams p, const long long total) {
+  using Acc = typename AccT<T>::type;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int mi = (int)(idx % p.minor);
+    long long t = idx / p.minor;
+    const int ox = (int)(t % p.out_w);
+    t /= p.out_w;
+    const int oy = (int)(t % p.out_h);
+    const long long mj = t / p.out_h;
+    const int by = oy * p.down_y - p.pad_y0;
+    const int bx = ox * p.down_x - p.pad_x0;
+    const T* pin = in + mj * (long long)p.in_h * p.in_w * p.minor + mi;
+    Acc v = 0;
+    for (int ky = 0; ky < p.kh; ++ky) {
+      const int uy = by + ky;
+      if (uy < 0 || (uy % p.up_y) != 0) continue;
+      const int iy = uy / p.up_y;
+      if (iy >= p.in_h) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        const int ux = bx + kx;
+        if (ux < 0 || (ux % p.up_x) != 0) continue;
+        const int ix = ux / p.up_x;
+        if (ix >= p.in_w) continue;
+        v += to_acc<T>(pin[((long long)iy * p.in_w + ix) * p.minor]) *
+             to_acc<T>(kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)]);
+      }
+    }
+    out[idx] = from_acc<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------- path 1: row-march (f32, up=down=1, k<=4x4, minor=1)
+struct RMParams {
+  int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw;
+  int th;       // output rows per wave, multiple of 4
+  int strips;   // 64*VEC-column strips per row
+  int tiles_y;  // row tiles per plane
+  long long total_waves;
+};
+
+template <int VEC> struct Row { float v[VEC + 3]; };
+
+template <int VEC>
+__device__ __forceinline__ void load_seg(float (&dst)[VEC], const float* __restrict__ rp, bool rowok, int a, int in_w) {
+  if (!rowok) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dst[e] = 0.f;
+  } else if (a >= 0 && a + VEC <= in_w) {
+    if constexpr (VEC == 4) {
+      const f32x4_u t = *reinterpret_cast<const f32x4_u*>(rp + a);
+      dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    } else if constexpr (VEC == 2) {
+      const f32x2_u t = *reinterpret_cast<const f32x2_u*>(rp + a);
+      dst[0] = t.x; dst[1] = t.y;
+    } else {
+      dst[0] = rp[a];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dst[e] = (a + e >= 0 && a + e < in_w) ? rp[a + e] : 0.f;
+  }
+}
+
+// Row `iy` of the plane, columns a0 .. a0+VEC+2 for this lane.  Lane l loads segment l
+// (VEC floats); the 3 halo columns are elements of segments l+1.. held by the next lanes; the
+// segments past lane 63 are loaded by lanes 0..NX-1 as an extra segment and rotated in.
+template <int VEC>
+__device__ __forceinline__ void load_row(Row<VEC>& r, const float* __restrict__ pin, int iy, bool need,
+                                         int in_h, int in_w, int a0, int lane) {
+  constexpr int NX = (3 + VEC - 1) / VEC;
+  const bool rowok = need && iy >= 0 && iy < in_h;  // wave-uniform
+  const float* rp = pin + (long long)iy * in_w;
+  float prim[VEC], extra[VEC];
+  load_seg<VEC>(prim, rp, rowok, a0, in_w);
+  if (lane < NX) {
+    load_seg<VEC>(extra, rp, rowok, a0 + 64 * VEC, in_w);
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) extra[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) r.v[e] = prim[e];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    constexpr int dummy = 0; (void)dummy;
+    const int e = VEC + j;
+    const int d = e / VEC;   // lane distance of the segment holding column a0+e
+    const int el = e % VEC;  // element inside that segment
+    const float t = (lane < d) ? extra[el] : prim[el];
+    r.v[e] = __shfl(t, (lane + d) & 63, 64);
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void emit_row(float* __restrict__ pout, int oy, int oy_end, int out_w, int c0,
+                                         const float (&kf)[4][4], const Row<VEC>& r0, const Row<VEC>& r1,
+                                         const Row<VEC>& r2, const Row<VEC>& r3) {
+  if (oy >= oy_end) return;  // wave-uniform
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float v = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) v = fmaf(r0.v[e + kx], kf[0][kx], v);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) v = fmaf(r1.v[e + kx], kf[1][kx], v);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) v = fmaf(r2.v[e + kx], kf[2][kx], v);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) v = fmaf(r3.v[e + kx], kf[3][kx], v);
+    acc[e] = v;
+  }
+  float* op = pout + (long long)oy * out_w + c0;
+  if (c0 + VEC <= out_w) {
+    if constexpr (VEC == 4) {
+      f32x4_u t; t.x = acc[0]; t.y = acc[1]; t.z = acc[2]; t.w = acc[3];
+      *reinterpret_cast<f32x4_u*>(op) = t;
+    } else if constexpr (VEC == 2) {
+      f32x2_u t; t.x = acc[0]; t.y = acc[1];
+      *reinterpret_cast<f32x2_u*>(op) = t;
+    } else {
+      op[0] = acc[0];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      if (c0 + e < out_w) op[e] = acc[e];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict__ in, const float* __restrict__ kern,
+                                                        float* __restrict__ out, const RMParams p) {
+  const int lane = threadIdx.x & 63;
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const long long gw = (long long)lb * 4 + (threadIdx.x >> 6);
+  if (gw >= p.total_waves) return;  // wave-uniform
+  const int strip = (int)(gw % p.strips);
+  const long long t = gw / p.strips;
+  const int ty = (int)(t % p.tiles_y);
+  const long long plane = t / p.tiles_y;
+
+  // flipped taps, zero-extended to 4x4 (wave-uniform -> SGPRs)
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+      kf[ky][kx] = (ky < p.kh && kx < p.kw) ? kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
+
+  const int c0 = (strip * 64 + lane) * VEC;
+  const int a0 = c0 - p.pad_x0;
+  const int oy0 = ty * p.th;
+  const int oy_end = min(oy0 + p.th, p.out_h);
+  const float* pin = in + plane * (long long)p.in_h * p.in_w;
+  float* pout = out + plane * (long long)p.out_h * p.out_w;
+  const int iy0 = oy0 - p.pad_y0;
+
+  Row<VEC> w0, w1, w2, w3;
+  load_row<VEC>(w0, pin, iy0 + 0, true, p.in_h, p.in_w, a0, lane);
+  load_row<VEC>(w1, pin, iy0 + 1, true, p.in_h, p.in_w, a0, lane);
+  load_row<VEC>(w2, pin, iy0 + 2, true, p.in_h, p.in_w, a0, lane);
+  for (int r = 0; r < p.th; r += 4) {
+    const int oy = oy0 + r;
+    if (oy >= oy_end) break;  // wave-uniform
+    load_row<VEC>(w3, pin, iy0 + r + 3, true, p.in_h, p.in_w, a0, lane);
+    emit_row<VEC>(pout, oy + 0, oy_end, p.out_w, c0, kf, w0, w1, w2, w3);
+    load_row<VEC>(w0, pin, iy0 + r + 4, oy + 1 < oy_end, p.in_h, p.in_w, a0, lane);
+    emit_row<VEC>(pout, oy + 1, oy_end, p.out_w, c0, kf, w1, w2, w3, w0);
+    load_row<VEC>(w1, pin, iy0 + r + 5, oy + 2 < oy_end, p.in_h, p.in_w, a0, lane);
+    emit_row<VEC>(pout, oy + 2, oy_end, p.out_w, c0, kf, w2, w3, w0, w1);
+    load_row<VEC>(w2, pin, iy0 + r + 6, oy + 3 < oy_end, p.in_h, p.in_w, a0, lane);
+    emit_row<VEC>(pout, oy + 3, oy_end, p.out_w, c0, kf, w3, w0, w1, w2);
+  }
+}
+
+template <typename T>
+int launch_generic(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
+  const long long total = (long long)p.major * p.out_h * p.out_w * p.minor;
+  if (total == 0) return FMGAN_OK;
+  long long blocks = (total + 255) / 256;
+  const long long cap = (long long)FMGAN_NUM_CU * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(ufd_generic<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)in, (const T*)kern, (T*)out, p, total);
+  return fmgan_check_launch();
+}
+
+bool rowmarch_ok(int dtype, const UfdParams& p) {
+  return dtype == FMGAN_F32 && p.minor == 1 && p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1 &&
+         p.kh <= 4 && p.kw <= 4 && p.out_w >= 64 && p.out_h >= 4;
+}
+
+int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
+  RMParams r;
+  r.planes = p.major; r.in_h = p.in_h; r.in_w = p.in_w; r.out_h = p.out_h; r.out_w = p.out_w;
+  r.pad_x0 = p.pad_x0; r.pad_y0 = p.pad_y0; r.kh = p.kh; r.kw = p.kw;
+  const int vec = p.out_w >= 192 ? 4 : (p.out_w >= 96 ? 2 : 1);
+  r.strips = (p.out_w + 64 * vec - 1) / (64 * vec);
+  // Largest row tile that still leaves >= 32 waves per CU in the grid (halo re-read = 3/TH).
+  const long long want = (long long)FMGAN_NUM_CU * 32;
+  int th = 64;
+  while (th > 4) {
+    const long long waves = (long long)p.major * r.strips * ((p.out_h + th - 1) / th);
+    if (waves >= want) break;
+    th >>= 1;
+  }
+  r.th = th;
+  r.tiles_y = (p.out_h + th - 1) / th;
+  r.total_waves = (long long)p.major * r.strips * r.tiles_y;
+  const long long blocks = (r.total_waves + 3) / 4;
+  if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+  const dim3 g((unsigned)blocks), b(256);
+  if (vec == 4) hipLaunchKernelGGL(ufd_rowmarch_f32<4>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
+  else if (vec == 2) hipLaunchKernelGGL(ufd_rowmarch_f32<2>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
+  else hipLaunchKernelGGL(ufd_rowmarch_f32<1>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
+  return fmgan_check_launch();
+}
+
+int validate(int dtype, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x,
+             int down_y) {
+  if (dtype != FMGAN_F32 && dtype != FMGAN_F64 && dtype != FMGAN_F16) return FMGAN_EUNSUPPORTED;
+  if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0) return FMGAN_EINVAL;
+  if (up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return FMGAN_EINVAL;
+  return FMGAN_OK;
+}
+
+}  // namespace
+
+extern "C" int fmgan_upfirdn2d_out_size(int in_h, int in_w, int kernel_h, int kernel_w, int up_x, int up_y, int down_x,
+                                        int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int* out_h,
+                                        int* out_w) {
+  if (!out_h || !out_w || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return FMGAN_EINVAL;
+  // op/upfirdn2d_kernel.cu:237-240
+  *out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h + down_y) / down_y;
+  *out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) / down_x;
+  return FMGAN_OK;
+}
+
+extern "C" int fmgan_upfirdn2d_select(int dtype, int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
+                                      int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                                      int pad_y1) {
+  int st = validate(dtype, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y);
+  if (st != FMGAN_OK) return st;
+  UfdParams p{major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, 0, 0};
+  fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
+                           &p.out_h, &p.out_w);
+  if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
+  if (rowmarch_ok(dtype, p)) return 1;
+  return 0;
+}
+
+extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel, void* out, int major, int in_h,
+                               int in_w, int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x,
+                               int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int force_path,
+                               void* stream) {
+  int st = validate(dtype, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y);
+  if (st != FMGAN_OK) return st;
+  UfdParams p{major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, 0, 0};
+  fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
+                           &p.out_h, &p.out_w);
+  if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
+  if (major == 0) return FMGAN_OK;
+  if (!input || !kernel || !out) return FMGAN_EINVAL;
+  if ((long long)in_h * in_w * minor > 0x7fffffffLL || (long long)p.out_h * p.out_w * minor > 0x7fffffffLL)
+    return FMGAN_EOVERFLOW;
+  hipStream_t s = (hipStream_t)stream;
+  int path = force_path;
+  if (path < 0) path = rowmarch_ok(dtype, p) ? 1 : 0;
+  switch (path) {
+    case 0:
+      if (dtype == FMGAN_F32) return launch_generic<float>(input, kernel, out, p, s);
+      if (dtype == FMGAN_F64) return launch_generic<double>(input, kernel, out, p, s);
+      return launch_generic<__half>(input, kernel, out, p, s);
+    case 1:
+      if (!rowmarch_ok(dtype, p)) return FMGAN_EUNSUPPORTED;
+      return launch_rowmarch(input, kernel, out, p, s);
+    default:
+      return FMGAN_EUNSUPPORTED;
+  }
+}

@@ -1,0 +1,211 @@
+"""ctypes binding of libfmgan_hip.so (include/fmgan_hip.h) — the only way the host code reaches a kernel.
+
+There is NO fallback: if the library is missing, or a tensor is not on the GPU, this raises.
+PyTorch is used for device memory and streams only; every launch goes on torch's current HIP stream
+of the tensor's device (as the reference launches on at::cuda::getCurrentCUDAStream,
+op/upfirdn2d_kernel.cu:213-215), asynchronously, so calls can be captured in a HIP graph.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libfmgan_hip.so')
+
+F32, F64, F16 = 0, 1, 2
+_DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16}
+
+_lib = None
+
+
+def _sig(fn, argtypes, restype=ctypes.c_int):
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the HIP extension is not built. Run `make -C {os.path.dirname(LIB_PATH)}` '
+            f'(or __graft_entry__.build()). There is no CPU or PyTorch fallback for these ops.')
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i, f, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+    _sig(L.fmgan_abi_version, [])
+    _sig(L.fmgan_status_string, [i], ctypes.c_char_p)
+    _sig(L.fmgan_upfirdn2d_select, [i] * 15)
+    _sig(L.fmgan_upfirdn2d_out_size, [i] * 12 + [ctypes.POINTER(i)] * 2)
+    _sig(L.fmgan_upfirdn2d, [i, vp, vp, vp] + [i] * 15 + [vp])
+    _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
+    _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
+    _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
+    _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, vp])
+    _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, vp])
+    _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
+    if L.fmgan_abi_version() != 1:
+        raise RuntimeError('libfmgan_hip.so ABI version mismatch')
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f'{what}: {lib().fmgan_status_string(status).decode()} (status {status})')
+
+
+def require_gpu(t, name):
+    # op/upfirdn2d.cpp:8 CHECK_CUDA — same exception type (RuntimeError) and wording
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA tensor (this build has no CPU path)')
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f'unsupported dtype {t.dtype}: float32/float64/float16 only') from None
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class on_device:
+    """Make the tensor's device current for the launch and hand out its current stream."""
+
+    def __init__(self, t):
+        self.dev = t.device
+        self.guard = None
+
+    def __enter__(self):
+        if torch.cuda.current_device() != self.dev.index:
+            self.guard = torch.cuda.device(self.dev)
+            self.guard.__enter__()
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
+# ----------------------------------------------------------------------------- raw ops (no autograd)
+def upfirdn2d_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    check(lib().fmgan_upfirdn2d_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1,
+                                         ctypes.byref(oh), ctypes.byref(ow)), 'upfirdn2d_out_size')
+    return oh.value, ow.value
+
+
+def upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, force_path=-1):
+    """Same positional signature and layout as the reference's pybind `upfirdn2d` (op/upfirdn2d.cpp:12-23):
+    input [major,in_h,in_w,minor], kernel [kh,kw] -> new tensor [major,out_h,out_w,minor]."""
+    require_gpu(input, 'input')
+    require_gpu(kernel, 'kernel')
+    x = input.contiguous()
+    k = kernel.to(dtype=x.dtype).contiguous()
+    major, in_h, in_w, minor = x.shape
+    kh, kw = k.shape
+    out_h, out_w = upfirdn2d_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+    if out_h <= 0 or out_w <= 0:
+        raise RuntimeError(f'upfirdn2d: empty output {out_h}x{out_w}')
+    out = torch.empty((major, out_h, out_w, minor), dtype=x.dtype, device=x.device)
+    with on_device(x) as stream:
+        check(lib().fmgan_upfirdn2d(dtype_code(x), ptr(x), ptr(k), ptr(out), major, in_h, in_w, minor, kh, kw,
+                                    up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, force_path, stream),
+              'upfirdn2d')
+    return out
+
+
+def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
+    """Same positional signature as the reference's pybind `fused_bias_act` (op/fused_bias_act.cpp:11-21);
+    empty `bias` / `refer` tensors mean "absent" (op/fused_bias_act_kernel.cu:62-63)."""
+    require_gpu(input, 'input')
+    if bias is not None and bias.numel():
+        require_gpu(bias, 'bias')
+    x = input.contiguous()
+    b = bias.to(dtype=x.dtype).contiguous() if bias is not None and bias.numel() else None
+    r = refer.to(dtype=x.dtype).contiguous() if refer is not None and refer.numel() else None
+    if r is not None and r.numel() != x.numel():
+        raise RuntimeError('fused_bias_act: refer must have as many elements as input')
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    out = torch.empty_like(x)
+    with on_device(x) as stream:
+        check(lib().fmgan_fused_bias_act(dtype_code(x), ptr(x), ptr(b), ptr(r), ptr(out), x.numel(),
+                                         0 if b is None else b.numel(), step_b, int(act), int(grad), float(alpha),
+                                         float(scale), stream), 'fused_bias_act')
+    return out
+
+
+def noise_bias_act(x, noise, noise_weight, bias, alpha, scale):
+    """lrelu(x + noise_weight*noise + bias[c]) * scale in one pass; x [B,C,H,W] f32, noise [1|B,1,H,W]."""
+    require_gpu(x, 'input')
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    nz = noise.contiguous() if noise is not None else None
+    nb = 1 if nz is None else nz.shape[0]
+    out = torch.empty_like(x)
+    with on_device(x) as stream:
+        check(lib().fmgan_noise_bias_act_f32(ptr(x), ptr(nz), ptr(noise_weight), ptr(bias), ptr(out), b, c, h * w, nb,
+                                             float(alpha), float(scale), stream), 'noise_bias_act')
+    return out
+
+
+def modconv_demod(weight, style, scale, eps=1e-8):
+    """weight [cout,cin,k,k] (or [1,cout,cin,k,k]) f32, style [B,cin] -> demod [B,cout]."""
+    cout, cin, kh, kw = weight.shape[-4:]
+    style = style.contiguous()
+    demod = torch.empty((style.shape[0], cout), dtype=torch.float32, device=style.device)
+    with on_device(style) as stream:
+        check(lib().fmgan_modconv_demod_f32(ptr(weight), ptr(style), ptr(demod), style.shape[0], cout, cin, kh * kw,
+                                            float(scale), float(eps), stream), 'modconv_demod')
+    return demod
+
+
+def modconv_weight_prep(weight, scale):
+    """[.., cout,cin,k,k] -> wt [cin, k*k, cout] = scale * weight, the MFMA A-operand layout."""
+    cout, cin, kh, kw = weight.shape[-4:]
+    wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=weight.device)
+    with on_device(weight) as stream:
+        check(lib().fmgan_modconv_weight_prep_f32(ptr(weight), ptr(wt), cout, cin, kh * kw, float(scale), stream),
+              'modconv_weight_prep')
+    return wt
+
+
+def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=None, fuse_act=False, alpha=0.2,
+              act_scale=2 ** 0.5):
+    """x [B,cin,H,W] f32, wt from modconv_weight_prep (3x3), style [B,cin], demod [B,cout] or None."""
+    require_gpu(x, 'input')
+    x = x.contiguous()
+    style = style.contiguous()
+    b, cin, h, w = x.shape
+    cout = wt.shape[2]
+    oh, ow = (2 * h + 1, 2 * w + 1) if mode == 1 else (h, w)
+    out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=x.device)
+    nz = noise.contiguous() if noise is not None else None
+    with on_device(x) as stream:
+        check(lib().fmgan_modconv2d_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), ptr(out), b, cin, cout, h, w, mode,
+                                        ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
+                                        int(bool(fuse_act)), float(alpha), float(act_scale), stream), 'modconv2d')
+    return out
+
+
+def torgb(x, weight, style, bias, skip, scale):
+    """x [B,cin,H,W] f32, weight [cout,cin] (any leading/trailing 1 dims), style [B,cin], bias [cout], skip [B,cout,H,W]."""
+    require_gpu(x, 'input')
+    x = x.contiguous()
+    style = style.contiguous()
+    b, cin, h, w = x.shape
+    cout = weight.numel() // cin
+    sk = skip.contiguous() if skip is not None else None
+    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+    with on_device(x) as stream:
+        check(lib().fmgan_torgb_f32(ptr(x), ptr(weight), ptr(style), ptr(bias), ptr(sk), ptr(out), b, cin, cout, h * w,
+                                    float(scale), stream), 'torgb')
+    return out

@@ -1,0 +1,114 @@
+"""Host side of the modulated-convolution kernels (fmgan_modconv_* / fmgan_torgb_f32 in include/fmgan_hip.h).
+
+Forward runs on the hand-written MFMA kernels.  The reference gets its gradients (to second order: path-length
+regularisation differentiates through Generator.forward with create_graph=True, stylegan2.py:683-688) from
+autograd over F.conv2d / F.conv_transpose2d.  Here the backward re-states the same op as a differentiable
+composite of PyTorch-ROCm ops *in the input-modulated form* (dense convs with batch-shared weights, no
+[B*Cout,Cin,3,3] weight materialisation) and lets autograd differentiate that, so any derivative order works.
+HIP backward kernels are the next step for this row.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import functional as F
+
+from . import _native
+
+
+def modconv_composite(x, weight, s, demodulate, mode, scale, eps=1e-8):
+    """y[b,o] = d[b,o] * conv(x[b,i] * s[b,i], scale * W[o,i]);  d = rsqrt(sum_i s^2 * sum_k (scale W)^2 + eps).
+    Algebraically the reference's ModulatedConv2d (stylegan2.py:257-293); differentiable torch ops only.
+    mode 0: pad k//2; mode 1: transposed stride 2 (-> 2H+1); mode 2: stride-2 valid conv (input pre-blurred)."""
+    cout, cin, k, _ = weight.shape[-4:]
+    w = weight.reshape(cout, cin, k, k) * scale
+    xs = x * s[:, :, None, None]
+    if mode == 1:
+        y = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2)
+    elif mode == 2:
+        y = F.conv2d(xs, w, stride=2)
+    else:
+        y = F.conv2d(xs, w, padding=k // 2)
+    if demodulate:
+        d = torch.rsqrt(s.pow(2) @ w.pow(2).sum([2, 3]).t() + eps)
+        y = y * d[:, :, None, None]
+    return y
+
+
+def _regrad(fn, saved, need, grad_out):
+    """Gradients of fn(*saved) w.r.t. the needed inputs; keeps the graph when called under create_graph."""
+    keep = torch.is_grad_enabled()
+    with torch.enable_grad():
+        ins = list(saved) if keep else [t.detach().requires_grad_(n) for t, n in zip(saved, need)]
+        y = fn(*ins)
+        sel = [t for t, n in zip(ins, need) if n and t.requires_grad]
+        grads = iter(torch.autograd.grad(y, sel, grad_out, create_graph=keep, allow_unused=True)) if sel else iter(())
+    return [next(grads) if (n and t.requires_grad) else None for t, n in zip(ins, need)]
+
+
+class ModulatedConv2dFunction(Function):
+    """3x3 modulated conv (mode 0) / transposed stride-2 conv (mode 1) on the MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s, wt, demodulate, mode, scale):
+        demod = _native.modconv_demod(weight, s, scale) if demodulate else None
+        out = _native.modconv2d(x, wt, s, demod, mode)
+        ctx.save_for_backward(x, weight, s)
+        ctx.cfg = (demodulate, mode, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        demodulate, mode, scale = ctx.cfg
+        gx, gw, gs = _regrad(lambda x, w, s: modconv_composite(x, w, s, demodulate, mode, scale),
+                             ctx.saved_tensors, ctx.needs_input_grad[:3], grad_out)
+        return gx, gw, gs, None, None, None, None
+
+
+def _torgb_composite(x, weight, s, bias, skip, scale):
+    y = modconv_composite(x, weight, s, False, 0, scale)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    if skip is not None:
+        y = y + skip
+    return y
+
+
+class ToRGBFunction(Function):
+    """1x1 modulated conv without demodulation + bias + skip add in one HBM pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s, bias, skip, scale):
+        out = _native.torgb(x, weight, s, bias, skip, scale)
+        ctx.has_skip = skip is not None
+        ctx.save_for_backward(x, weight, s, bias, *([skip] if ctx.has_skip else []))
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, s, bias = ctx.saved_tensors[:4]
+        scale = ctx.scale
+        gx, gw, gs = _regrad(lambda a, b, c: modconv_composite(a, b, c, False, 0, scale), (x, weight, s),
+                             ctx.needs_input_grad[:3], grad_out)
+        gb = grad_out.sum([0, 2, 3]).view(bias.shape) if ctx.needs_input_grad[3] else None
+        gk = grad_out if (ctx.has_skip and ctx.needs_input_grad[4]) else None
+        return gx, gw, gs, gb, gk, None
+
+
+def hip_conv_ok(x, weight):
+    return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[-1] == 3
+
+
+def modulated_conv2d(x, weight, s, wt, demodulate, mode, scale):
+    """Dispatch: f32 3x3 -> MFMA kernel; anything else the reference allows (other kernel sizes, f64 for
+    gradcheck, the unused downsample branch) -> the PyTorch-ROCm composite.  Both run on the GPU."""
+    _native.require_gpu(x, 'input')
+    if mode in (0, 1) and hip_conv_ok(x, weight):
+        return ModulatedConv2dFunction.apply(x, weight, s, wt, demodulate, mode, scale)
+    return modconv_composite(x, weight, s, demodulate, mode, scale)
+
+
+def to_rgb(x, weight, s, bias, skip, scale):
+    _native.require_gpu(x, 'input')
+    if x.dtype == torch.float32 and weight.shape[-1] == 1 and weight.shape[-4] <= 4:
+        return ToRGBFunction.apply(x, weight, s, bias, skip, scale)
+    return _torgb_composite(x, weight, s, bias, skip, scale)

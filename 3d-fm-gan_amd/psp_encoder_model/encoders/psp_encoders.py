@@ -1,0 +1,76 @@
+"""pSp W+ encoder E_W_Plus (reference: psp_encoder_model/encoders/psp_encoders.py:20-132).
+
+IR-SE backbone with a 3-level feature pyramid; each of the n_styles heads reduces its pyramid level to 1x1 with
+stride-2 convs and maps it through an EqualLinear.  Host PyTorch-ROCm (MIOpen); same constructor and state_dict
+names as the reference.  The two Backbone* encoders of the reference file are not on the 3-encoder path and are
+not provided.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
+
+from .helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
+from stylegan2 import EqualLinear
+
+_TAPS = {18: (3, 5, 7), 50: (6, 20, 23)}   # units whose outputs feed the pyramid (psp_encoders.py:105-108)
+
+
+class GradualStyleBlock(Module):
+    """log2(spatial) x (conv3x3/2 + LeakyReLU) down to 1x1, then EqualLinear (psp_encoders.py:20-41)."""
+
+    def __init__(self, in_c, out_c, spatial):
+        super().__init__()
+        self.out_c = out_c
+        self.spatial = spatial
+        layers, c = [], in_c
+        for _ in range(int(math.log2(spatial))):
+            layers += [Conv2d(c, out_c, kernel_size=3, stride=2, padding=1), nn.LeakyReLU()]
+            c = out_c
+        self.convs = nn.Sequential(*layers)
+        self.linear = EqualLinear(out_c, out_c, lr_mul=1)
+
+    def forward(self, x):
+        return self.linear(self.convs(x).view(-1, self.out_c))
+
+
+class GradualStyleEncoder(Module):
+    def __init__(self, num_layers, mode='ir', opts=None):
+        super().__init__()
+        assert num_layers in [18, 50, 100, 152], 'num_layers should be 18, 50, 100, or 152'
+        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
+        self.num_layers = num_layers
+        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE
+        self.input_layer = Sequential(Conv2d(opts.input_nc, 64, (3, 3), 1, 1, bias=False), BatchNorm2d(64), PReLU(64))
+        self.body = Sequential(*[unit(b.in_channel, b.depth, b.stride) for stage in get_blocks(num_layers) for b in stage])
+        self.style_count = opts.n_styles
+        self.coarse_ind = 3
+        self.middle_ind = 7
+        self.styles = nn.ModuleList()
+        for i in range(self.style_count):
+            spatial = 16 if i < self.coarse_ind else (32 if i < self.middle_ind else 64)
+            self.styles.append(GradualStyleBlock(512, 512, spatial))
+        self.latlayer1 = nn.Conv2d(256, 512, kernel_size=1, stride=1, padding=0)
+        self.latlayer2 = nn.Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
+
+    def _upsample_add(self, x, y):
+        """Bilinear (align_corners) resize of x to y's size, plus y (psp_encoders.py:82-98)."""
+        return F.interpolate(x, size=y.shape[2:], mode='bilinear', align_corners=True) + y
+
+    def forward(self, x):
+        x = self.input_layer(x)
+        t1, t2, t3 = _TAPS[self.num_layers]
+        feats = {}
+        for i, unit in enumerate(self.body):
+            x = unit(x)
+            if i in (t1, t2, t3):
+                feats[i] = x
+        c1, c2, c3 = feats[t1], feats[t2], feats[t3]
+        latents = [self.styles[j](c3) for j in range(min(self.coarse_ind, self.style_count))]
+        p2 = self._upsample_add(c3, self.latlayer1(c2))
+        latents += [self.styles[j](p2) for j in range(self.coarse_ind, min(self.middle_ind, self.style_count))]
+        p1 = self._upsample_add(p2, self.latlayer2(c1))
+        latents += [self.styles[j](p1) for j in range(self.middle_ind, self.style_count)]
+        return torch.stack(latents, dim=1)

@@ -1,0 +1,163 @@
+/*
+ * fmgan_hip.h — C-ABI of libfmgan_hip.so: the MI355X (gfx950) kernels behind the
+ * 3D-FM GAN forward hot path `(photo, render) -> image`.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers,
+ * sizes and a `hipStream_t` (passed as void*), launches asynchronously on that
+ * stream, never allocates, never synchronises, keeps no global state and is
+ * re-entrant (one call per Python thread / per rank is fine).  The caller owns
+ * all buffers; outputs must be pre-allocated (the reference allocates inside the
+ * op with at::empty — here the host-side shim does that).
+ *
+ * Return value: FMGAN_OK (0) or a negative FMGAN_E* code.  The reference checks
+ * only "is a CUDA tensor" (op/upfirdn2d.cpp:8,15-16, op/fused_bias_act.cpp:7,13-14)
+ * and never calls cudaGetLastError; this library additionally validates shapes
+ * and reports launch failures, and the Python shim turns any non-zero status into
+ * RuntimeError (same exception type as TORCH_CHECK).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo root):
+ *   fmgan_upfirdn2d        <- upfirdn2d_op()        op/upfirdn2d_kernel.cu:209-369
+ *                             (pybind `upfirdn2d`    op/upfirdn2d.cpp:12-23)
+ *   fmgan_fused_bias_act   <- fused_bias_act_op()   op/fused_bias_act_kernel.cu:52-99
+ *                             (pybind `fused_bias_act` op/fused_bias_act.cpp:11-21)
+ *   fmgan_modconv_demod,
+ *   fmgan_modconv2d        <- ModulatedConv2d.forward  stylegan2.py:250-298
+ *                             (F.conv2d / F.conv_transpose2d with groups=batch)
+ *   fmgan_torgb            <- ToRGB.forward            stylegan2.py:389-404
+ */
+#ifndef FMGAN_HIP_H
+#define FMGAN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMGAN_ABI_VERSION 1
+
+/* status codes */
+#define FMGAN_OK            0
+#define FMGAN_EINVAL       -1   /* null pointer / non-positive or inconsistent dims */
+#define FMGAN_EUNSUPPORTED -2   /* dtype / act / mode outside what the reference dispatches */
+#define FMGAN_ELAUNCH      -3   /* hipGetLastError() != hipSuccess after the launch */
+#define FMGAN_EOVERFLOW    -4   /* an element count does not fit the kernel's index type */
+
+/* element types (the reference dispatches float/double/half:
+ * op/upfirdn2d_kernel.cu:311, op/fused_bias_act_kernel.cu:79) */
+#define FMGAN_F32 0
+#define FMGAN_F64 1
+#define FMGAN_F16 2
+
+int         fmgan_abi_version(void);
+const char *fmgan_status_string(int status);
+
+/* Which upfirdn2d kernel `fmgan_upfirdn2d` would pick for these arguments:
+ * 0 generic, 1 row-march (up=down=1, wide rows), 2 LDS plane-tile (up=down=1,
+ * small planes), 3 up=2 polyphase, 5 down=2.  Pure host logic, no GPU needed.
+ * `force_path` in fmgan_upfirdn2d uses the same numbering (-1 = automatic). */
+int fmgan_upfirdn2d_select(int dtype, int major, int in_h, int in_w, int minor,
+                           int kernel_h, int kernel_w, int up_x, int up_y,
+                           int down_x, int down_y, int pad_x0, int pad_x1,
+                           int pad_y0, int pad_y1);
+
+/* out_h/out_w exactly as upfirdn2d_op computes them (op/upfirdn2d_kernel.cu:237-240). */
+int fmgan_upfirdn2d_out_size(int in_h, int in_w, int kernel_h, int kernel_w,
+                             int up_x, int up_y, int down_x, int down_y,
+                             int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                             int *out_h, int *out_w);
+
+/*
+ * upfirdn2d: zero-stuff by (up_y,up_x), pad/crop by (pad_*; negative = crop),
+ * correlate with the FLIPPED `kernel` (i.e. true convolution), keep every
+ * (down_y,down_x)-th sample.
+ *   input  [major, in_h, in_w, minor]   contiguous, `dtype`
+ *   kernel [kernel_h, kernel_w]         contiguous, `dtype` (un-flipped, as the caller holds it)
+ *   out    [major, out_h, out_w, minor] contiguous, `dtype`, pre-allocated
+ * Semantics: op/upfirdn2d_kernel.cu:107-207 (== upfirdn2d_native, op/upfirdn2d.py:168-209).
+ * force_path: -1 automatic; otherwise a path number from fmgan_upfirdn2d_select
+ * (FMGAN_EUNSUPPORTED if that path cannot serve the arguments) — used by tests/bench.
+ */
+int fmgan_upfirdn2d(int dtype, const void *input, const void *kernel, void *out,
+                    int major, int in_h, int in_w, int minor,
+                    int kernel_h, int kernel_w,
+                    int up_x, int up_y, int down_x, int down_y,
+                    int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                    int force_path, void *stream);
+
+/*
+ * fused_bias_act: out[i] = act'(x[i] + bias[(i / step_b) % size_b]; refer[i]) * scale
+ *   act*10+grad: 10,11 linear; 12 zero; 30 lrelu(x); 31 (refer>0 ? x : alpha*x); 32 zero
+ *   (op/fused_bias_act_kernel.cu:36-45).  bias == NULL or size_b == 0: no bias;
+ *   refer == NULL: refer treated as 0 (the reference passes an empty tensor).
+ *   x, refer, out: `size_x` contiguous elements of `dtype`; bias: `size_b` elements.
+ *   step_b = product of x.shape[2:] (op/fused_bias_act_kernel.cu:67-71).
+ */
+int fmgan_fused_bias_act(int dtype, const void *x, const void *bias, const void *refer,
+                         void *out, long long size_x, int size_b, int step_b,
+                         int act, int grad, float alpha, float scale, void *stream);
+
+/*
+ * StyledConv epilogue in one pass (stylegan2.py:360-376: NoiseInjection then FusedLeakyReLU):
+ *   out[b,c,p] = lrelu(x[b,c,p] + noise_weight[0] * noise[b or 0, p] + bias[c]) * scale
+ *   x/out [batch, channel, hw] f32; noise [noise_batch (1 or batch), hw] f32 or NULL;
+ *   noise_weight device scalar f32 (NoiseInjection.weight, stylegan2.py:305) or NULL; bias [channel] or NULL.
+ */
+int fmgan_noise_bias_act_f32(const float *x, const float *noise, const float *noise_weight,
+                             const float *bias, float *out,
+                             int batch, int channel, int hw, int noise_batch,
+                             float alpha, float scale, void *stream);
+
+/*
+ * Demodulation coefficients of ModulatedConv2d (stylegan2.py:258-262):
+ *   demod[b,o] = rsqrt( sum_{i,k} (scale * weight[o,i,k] * style[b,i])^2 + eps )
+ *   weight [cout, cin, ktaps] f32 (the [1,cout,cin,k,k] parameter), style [batch, cin] f32,
+ *   demod [batch, cout] f32.  One wave per output channel; the sum over cin is a wave-shuffle reduction.
+ */
+int fmgan_modconv_demod_f32(const float *weight, const float *style, float *demod,
+                            int batch, int cout, int cin, int ktaps,
+                            float scale, float eps, void *stream);
+
+/*
+ * Weight layout for the MFMA contraction: wt[i][tap][o] = scale * weight[o][i][tap]
+ * (o contiguous, so a 32-lane MFMA A-operand read is one LDS bank row and staging is coalesced).
+ *   weight [cout, cin, ktaps] f32, wt [cin, ktaps, cout] f32 pre-allocated.
+ * Depends on the parameter only — the host shim caches it per parameter version.
+ */
+int fmgan_modconv_weight_prep_f32(const float *weight, float *wt, int cout, int cin, int ktaps,
+                                  float scale, void *stream);
+
+/*
+ * Modulated 3x3 convolution, input-modulated form with batch-shared weights
+ * (algebraically equal to the reference's per-sample weight-modulated grouped conv,
+ * stylegan2.py:258-293):
+ *   mode 0 (plain, stylegan2.py:289-293): out[b,o,y,x] = demod[b,o] * sum_{i,ky,kx}
+ *             wt[i,ky*3+kx,o] * style[b,i] * in[b,i,y+ky-1,x+kx-1]                 out [b,o,h,w]
+ *   mode 1 (transposed, stride 2, pad 0; stylegan2.py:268-277):                    out [b,o,2h+1,2w+1]
+ *             out[b,o,Y,X] = demod[b,o] * sum_{i, 2y+ky=Y, 2x+kx=X} wt[i,ky*3+kx,o]*style[b,i]*in[b,i,y,x]
+ *   in [batch,cin,h,w], wt from fmgan_modconv_weight_prep_f32 (ktaps = 9), style [batch,cin],
+ *   demod [batch,cout] or NULL (no demodulation); out pre-allocated; all f32 contiguous.
+ * Optional fused StyledConv epilogue (mode 0 only; stylegan2.py:371-373), enabled by fuse_act != 0:
+ *   out = lrelu( (conv + noise_weight[0]*noise[b or 0,y,x]) + bias[o] ) * act_scale
+ *   noise [noise_batch (1 or batch), h*w] or NULL, noise_weight device scalar or NULL, bias [cout] or NULL.
+ * The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).
+ */
+int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
+                        const float *demod, float *out,
+                        int batch, int cin, int cout, int h, int w, int mode,
+                        const float *noise, const float *noise_weight, const float *bias,
+                        int noise_batch, int fuse_act, float alpha, float act_scale,
+                        void *stream);
+
+/*
+ * ToRGB (stylegan2.py:389-404): 1x1 modulated conv without demodulation + bias + optional skip:
+ *   out[b,c,p] = sum_i scale*weight[c,i]*style[b,i]*in[b,i,p] + bias[c] (+ skip[b,c,p])
+ *   in [batch,cin,hw], weight [cout,cin], style [batch,cin], bias [cout] or NULL,
+ *   skip [batch,cout,hw] or NULL (already upsampled), out [batch,cout,hw]; cout <= 4.
+ */
+int fmgan_torgb_f32(const float *in, const float *weight, const float *style,
+                    const float *bias, const float *skip, float *out,
+                    int batch, int cin, int cout, int hw, float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMGAN_HIP_H */
