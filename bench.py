@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — (photo, render) pairs/s of the 3D-FM GAN forward hot path on MI355X, with the upfirdn2d roofline.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one forward of the hot path over one batch of synthetic (photo, render) pairs per GPU:
+E_Tsr + E_W + E_W_Plus on 256^2 images -> co-modulation -> Generator -> image, fp32, eval-mode BatchNorm, no_grad.
+Default workload `pairs1024` is BASELINE config 4's per-GPU shard (B=8/GPU, Generator(1024), 18 styles — encoders on
+256^2), the configuration the headline upfirdn2d call ([B*32,1025,1025] -> [B*32,1024,1024]) lives in;
+`pairs256` (B=32/GPU, Generator(256)) is timed in the same run and reported as `pairs_per_s_256`.
+Forward shards over ranks by batch with no collective: weak scaling, value = all ranks' pairs / max time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, '3d-fm-gan_amd'), os.path.join(ROOT, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+WORKLOADS = {
+    'pairs1024': dict(size=1024, batch=8, desc='cfg4 shard: E_Tsr+E_W+E_W_Plus(18 styles) on 256^2 -> co-mod -> '
+                      'Generator(1024) forward, fp32, B=8/GPU'),
+    'pairs256': dict(size=256, batch=32, desc='E_Tsr+E_W+E_W_Plus(14 styles) on 256^2 -> co-mod -> Generator(256) '
+                     'forward, fp32, B=32/GPU'),
+}
+
+
+class LaunchTimer:
+    """HIP events on the launch stream (torch's current stream IS the stream _native launches on) around the
+    launches selected by `want`; times are read after the region has been synchronised."""
+
+    def __init__(self, want):
+        self.want = want
+        self.pairs = []
+
+    def begin(self, name, info):
+        if not self.want(name, info):
+            return None
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        return (name, info, s)
+
+    def end(self, tok):
+        if tok is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.append(tok + (e,))
+
+    def summary(self):
+        out = {}
+        for name, info, s, e in self.pairs:
+            out.setdefault((name, info), []).append(s.elapsed_time(e))
+        return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+
+
+def build_models(size, device):
+    import stylegan2
+    import resnet_encoder
+    from psp_encoder_model.encoders import psp_encoders
+    n_latent = int(round(__import__('math').log2(size))) * 2 - 2
+    torch.manual_seed(0)
+    nets = dict(
+        e_tsr=resnet_encoder.resnet18(tensor_encoding=True, tensor_transform=False),
+        e_w=resnet_encoder.resnet18(tensor_encoding=False, tensor_transform=False),
+        e_wp=psp_encoders.GradualStyleEncoder(18, 'ir_se', types.SimpleNamespace(input_nc=3, n_styles=n_latent)),
+        g=stylegan2.Generator(size, 512, 8),
+    )
+    for m in nets.values():
+        m.eval().requires_grad_(False)
+    return {k: m.to(device) for k, m in nets.items()}
+
+
+def make_step(nets, batch, device, rank):
+    from Util.network_util import Forward_Inference_3_Encoder
+    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)     # resident in HBM before timing
+    render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+
+    def step():
+        with torch.no_grad():
+            return Forward_Inference_3_Encoder(photo, render, nets['e_tsr'], nets['e_w'], nets['e_wp'], nets['g'])
+
+    return step, (photo, render)
+
+
+def timed(step, steps, warmup, world):
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt
+
+
+def cpu_baseline(nets, inputs, size, budget_s=20.0):
+    """The reference's pure-PyTorch CPU path as restated in oracle/torch_oracle.py (pinned to the reference by
+    tests/test_oracle_golden.py), on this box's host cores, B=1 pairs of the same workload until ~budget_s."""
+    from oracle import torch_oracle as T
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sds = {k: {n: v.detach().cpu() for n, v in m.state_dict().items()} for k, m in nets.items()}
+    photo, render = (t[:1].cpu() for t in inputs)
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            T.forward_inference_3_encoder(photo, render, sds['e_tsr'], sds['e_w'], sds['e_wp'], sds['g'], size)
+            n += 1
+            if time.perf_counter() - t0 > budget_s or n >= 16:
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit='pairs/s', cores=cores, kind='port',
+                sample=f'{n} pairs at B=1 through oracle/torch_oracle.py (reference CPU path restated: F.conv2d '
+                       f'modconv + upfirdn2d_native + CPU fused_leaky_relu), Generator({size}), {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='pairs1024', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='pairs per GPU (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true')
+    args = ap.parse_args()
+
+    from Miscellaneous import distributed as D
+    from op import _native
+    rank, world, device = D.init_distributed()
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    _native.lib()
+
+    wl = WORKLOADS[args.workload]
+    batch = args.batch or wl['batch']
+    nets = build_models(wl['size'], device)
+    step, inputs = make_step(nets, batch, device, rank)
+
+    # headline kernel: the last (largest) blur of the workload; timed with HIP events inside the timed region
+    r = wl['size']
+    head = (batch * nets['g'].channels[r], r + 1, r + 1, r, r, 1, 1, 4)
+    timer = LaunchTimer(lambda name, info: name == 'upfirdn2d' and info == head)
+    for _ in range(args.warmup):
+        step()
+    _native.set_observer(timer)
+    dt = timed(step, args.steps, 0, world)
+    _native.set_observer(None)
+    pairs_per_s = world * batch * args.steps / dt
+
+    out = {
+        'metric': '(photo,render) pairs/sec', 'value': pairs_per_s, 'unit': 'pairs/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
+                   'image_size': wl['size'], 'parallelism': f'replicas x{world} (batch-sharded, no collective)'},
+    }
+
+    # roofline of the dominant HBM kernel (upfirdn2d headline call), algorithmic bytes = 4*(in + out)
+    summ = timer.summary()
+    if (('upfirdn2d', head) in summ):
+        ms, n = summ[('upfirdn2d', head)]
+        bytes_alg = 4.0 * head[0] * (head[1] * head[2] + head[3] * head[4])
+        ach = bytes_alg / (ms * 1e-3) / 1e9
+        out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_rowmarch_f32<4> [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
+                           'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                           'traffic': None, 'avg_launch_ms': ms, 'launches': n, 'algorithmic_bytes': bytes_alg}
+
+    # per-kernel breakdown (separate, fully instrumented pass; not part of `value`)
+    full = LaunchTimer(lambda name, info: True)
+    _native.set_observer(full)
+    step()
+    torch.cuda.synchronize()
+    _native.set_observer(None)
+    fs = full.summary()
+    tot = {}
+    for (name, info), (ms, n) in fs.items():
+        tot[name] = tot.get(name, 0.0) + ms * n
+    conv = [(info, ms) for (name, info), (ms, n) in fs.items() if name == 'modconv2d']
+    if conv:
+        def flops(i):
+            b, cin, cout, h, w, mode = i
+            return 2.0 * 9 * cin * cout * b * h * w
+        best = max(conv, key=lambda t: flops(t[0]))
+        tf = flops(best[0]) / (best[1] * 1e-3) / 1e12
+        tot_tf = sum(flops(i) for i, _ in conv) / (sum(ms for _, ms in conv) * 1e-3) / 1e12
+        out['roofline_modconv'] = {'bound': 'mfma', 'kernel': f'modconv_mfma_f32 {best[0]}', 'achieved': tf,
+                                   'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP32_MFMA_PEAK_TF,
+                                   'all_layers_achieved': tot_tf}
+    out['ms_by_op_instrumented'] = {k: round(v, 3) for k, v in sorted(tot.items())}
+
+    if not args.no_secondary and args.workload == 'pairs1024':
+        del nets, step, inputs
+        torch.cuda.empty_cache()
+        wl2 = WORKLOADS['pairs256']
+        nets2 = build_models(wl2['size'], device)
+        step2, _ = make_step(nets2, wl2['batch'], device, rank)
+        dt2 = timed(step2, args.steps, args.warmup, world)
+        out['pairs_per_s_256'] = world * wl2['batch'] * args.steps / dt2
+        out['ms_per_step_256'] = 1e3 * dt2 / args.steps
+        out['config']['secondary'] = f"pairs256: {wl2['desc']}"
+        del nets2, step2
+        torch.cuda.empty_cache()
+        nets = build_models(wl['size'], device)
+        _, inputs = make_step(nets, 1, device, rank)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(nets, inputs, wl['size'])
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,177 @@
+"""CPU tests of the boundary and the host logic: the C-ABI library loads and exports every symbol the header
+declares, pure-host entry points behave, the product has NO CPU path, and the product modules keep the
+reference's parameter/buffer names and shapes (manifests captured from the reference)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import cases
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from op import _native
+    return _native.lib()
+
+
+def test_library_exports_header_symbols():
+    hdr = open(os.path.join(ROOT, 'include', 'fmgan_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = sorted(set(re.findall(r'\b(fmgan_\w+)\s*\(', hdr)))
+    assert len(names) >= 11
+    L = _lib()
+    for n in names:
+        assert hasattr(L, n), f'{n} declared in include/fmgan_hip.h but not exported'
+    assert L.fmgan_abi_version() == 1
+    assert L.fmgan_status_string(0) == b'ok'
+    assert b'invalid' in L.fmgan_status_string(-1)
+
+
+def test_out_size_matches_reference_formula():
+    from op import _native
+    for c in cases.UPFIRDN2D_CASES:
+        k = cases.make_fir(c['kernel'])
+        h, w = c['shape'][2:]
+        p0, p1 = c['pad']
+        oh, ow = _native.upfirdn2d_out_size(h, w, k.shape[0], k.shape[1], c['up'], c['up'], c['down'], c['down'],
+                                           p0, p1, p0, p1)
+        # op/upfirdn2d.py:112-113
+        assert oh == (h * c['up'] + p0 + p1 - k.shape[0]) // c['down'] + 1
+        assert ow == (w * c['up'] + p0 + p1 - k.shape[1]) // c['down'] + 1
+
+
+def test_path_selection_is_host_logic():
+    L = _lib()
+    # headline blur [256,1025,1025] -> row-march; 9x9 plane -> not row-march; f64 -> generic; bad args -> EINVAL
+    assert L.fmgan_upfirdn2d_select(0, 256, 1025, 1025, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) == 1
+    assert L.fmgan_upfirdn2d_select(0, 1024, 9, 9, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) != 1
+    assert L.fmgan_upfirdn2d_select(1, 256, 1025, 1025, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) == 0
+    assert L.fmgan_upfirdn2d_select(0, 1, 0, 8, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) == -1
+    assert L.fmgan_upfirdn2d_select(7, 1, 8, 8, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) == -2
+
+
+def test_invalid_arguments_return_status_without_gpu():
+    L = _lib()
+    # null pointers / bad dims are rejected before any HIP call
+    assert L.fmgan_upfirdn2d(0, None, None, None, 1, 8, 8, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, -1, None) == -1
+    assert L.fmgan_upfirdn2d(0, None, None, None, 1, 8, 8, 1, 4, 4, 0, 1, 1, 1, 1, 1, 1, 1, -1, None) == -1
+    assert L.fmgan_fused_bias_act(0, None, None, None, None, 16, 0, 1, 3, 0, 0.2, 1.4, None) == -1
+    assert L.fmgan_fused_bias_act(9, None, None, None, None, 16, 0, 1, 3, 0, 0.2, 1.4, None) == -2
+    assert L.fmgan_modconv2d_f32(None, None, None, None, None, 1, 8, 8, 4, 4, 3, None, None, None, 1, 0, 0.2, 1.4, None) == -2
+    assert L.fmgan_modconv2d_f32(None, None, None, None, None, 1, 8, 8, 4, 4, 0, None, None, None, 1, 0, 0.2, 1.4, None) == -1
+    assert L.fmgan_torgb_f32(None, None, None, None, None, None, 1, 8, 5, 16, 1.0, None) == -1
+    # empty batch is a no-op
+    assert L.fmgan_upfirdn2d(0, None, None, None, 0, 8, 8, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, -1, None) == 0
+
+
+def test_product_has_no_cpu_path():
+    from op import upfirdn2d, fused_leaky_relu, FusedLeakyReLU
+    x = torch.randn(1, 2, 8, 8)
+    k = cases.make_fir('blur')
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        upfirdn2d(x, k, pad=(1, 1))
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        fused_leaky_relu(x, torch.zeros(2))
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        FusedLeakyReLU(2)(x)
+    import stylegan2
+    g = stylegan2.Generator(16, 512, 1, generator_net_shape=[8, 8, 8, 8, 8, 8])
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        g(None, latent_styles=[torch.randn(1, g.n_latent, 512)], input_is_latent=True,
+          use_external_input_tensor=True, external_input_tensor=torch.randn(1, 8, 4, 4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, '3d-fm-gan_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('# oracle', ''), f'{f} mentions the oracle'
+
+
+def _check_manifest(module, man):
+    sd = module.state_dict()
+    assert list(sd.keys()) == sorted(sd.keys(), key=list(sd.keys()).index)  # trivial, keeps order explicit
+    assert set(sd.keys()) == set(man.keys()), (set(sd.keys()) ^ set(man.keys()))
+    for k, shape in man.items():
+        assert list(sd[k].shape) == shape, k
+
+
+def test_generator_state_dict_matches_reference(golden):
+    import stylegan2
+    man = golden.manifest('generator')
+    for c in cases.GENERATOR_CASES:
+        if c['size'] > 256:
+            continue
+        g = stylegan2.Generator(c['size'], 512, c['n_mlp'], generator_net_shape=c['shape'])
+        _check_manifest(g, man[c['name']])
+        assert g.n_latent == int(torch.log2(torch.tensor(float(c['size'])))) * 2 - 2
+    g = stylegan2.Generator(256, 512, 8)
+    assert len(g.state_dict()) == 135   # SURVEY.md §5 checkpoint row
+    assert tuple(g.state_dict()['conv1.conv.weight'].shape) == (1, 512, 512, 3, 3)
+
+
+def test_module_state_dicts_match_reference(golden):
+    import stylegan2
+    man = golden.manifest('modules')
+    for c in cases.MODCONV_CASES:
+        _check_manifest(stylegan2.ModulatedConv2d(c['cin'], c['cout'], c['k'], 512, demodulate=c['demod'],
+                                                  upsample=c['up']), man[c['name']])
+    for c in cases.STYLEDCONV_CASES:
+        _check_manifest(stylegan2.StyledConv(c['cin'], c['cout'], 3, 512, upsample=c['up']), man[c['name']])
+    for c in cases.TORGB_CASES:
+        _check_manifest(stylegan2.ToRGB(c['cin'], 512, upsample=c['skip']), man[c['name']])
+
+
+def test_discriminator_and_encoder_state_dicts_match_reference(golden):
+    import types
+    import stylegan2
+    import resnet_encoder
+    from psp_encoder_model.encoders import psp_encoders
+    _check_manifest(stylegan2.Discriminator(64), golden.manifest('discriminator')['d64'])
+    man = golden.manifest('encoders')
+    _check_manifest(resnet_encoder.resnet18(tensor_encoding=True, tensor_transform=False), man['resnet'])
+    _check_manifest(resnet_encoder.resnet18(tensor_encoding=False), man['resnet'])
+    for n in (14, 18):
+        opts = types.SimpleNamespace(input_nc=3, n_styles=n)
+        _check_manifest(psp_encoders.GradualStyleEncoder(18, 'ir_se', opts), man[f'psp{n}'])
+
+
+def test_encoders_match_golden_on_cpu(golden):
+    """The encoders are plain PyTorch modules (no custom kernel), so they also run on CPU: check the product's
+    modules against the reference's outputs here; the GPU run repeats this on MIOpen."""
+    import types
+    import numpy as np
+    import resnet_encoder
+    from psp_encoder_model.encoders import psp_encoders
+    g = golden('e2e')
+    name = 'e2e_256'
+    p = synth.tensor(name + '/photo', (1, 3, 256, 256), dist='uniform')
+    r = synth.tensor(name + '/render', (1, 3, 256, 256), dist='uniform')
+    e_tsr = resnet_encoder.resnet18(tensor_encoding=True)
+    e_w = resnet_encoder.resnet18(tensor_encoding=False)
+    e_wp = psp_encoders.GradualStyleEncoder(18, 'ir_se', types.SimpleNamespace(input_nc=3, n_styles=14))
+    for kind, m, seed in (('resnet', e_tsr, 5), ('resnet', e_w, 6), ('psp', e_wp, 7)):
+        m.load_state_dict(synth.state_dict(kind, m.state_dict(), seed=seed))
+        m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(e_tsr(p).numpy(), g[name + '/e_tsr'], atol=2e-4, rtol=2e-4)
+        np.testing.assert_allclose(e_w(r).numpy(), g[name + '/e_w'], atol=2e-4, rtol=2e-4)
+        ref = g[name + '/e_wplus']
+        np.testing.assert_allclose(e_wp(p).numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=2e-4)
+
+
+def test_network_shape_helpers():
+    import stylegan2
+    from Util import network_util
+    shape = [16, 16, 16, 16, 16, 16, 8, 8, 8, 8]
+    g = stylegan2.Generator(64, 512, 2, generator_net_shape=shape)
+    assert network_util.Get_Network_Shape(g.state_dict()) == shape
+    g2 = network_util.Build_Generator_From_Dict(g.state_dict(), size=64, n_mlp=2)
+    assert [tuple(v.shape) for v in g2.state_dict().values()] == [tuple(v.shape) for v in g.state_dict().values()]

@@ -1,0 +1,149 @@
+"""GPU parity tests for the modulated convolution / ToRGB kernels and the modules built on them."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def _tol(ref, k=2e-5):
+    return dict(atol=k * max(1.0, float(np.abs(ref).max())), rtol=1e-5)
+
+
+def _load(module, kind, seed):
+    module.load_state_dict(synth.state_dict(kind, module.state_dict(), seed=seed))
+    return module.to(dev())
+
+
+@pytest.mark.parametrize('c', cases.MODCONV_CASES, ids=lambda c: c['name'])
+def test_modulated_conv_golden(c, golden):
+    import stylegan2
+    g = golden('modules')
+    m = _load(stylegan2.ModulatedConv2d(c['cin'], c['cout'], c['k'], 512, demodulate=c['demod'], upsample=c['up']),
+              'generator', 1)
+    x = synth.tensor(c['name'] + '/x', (c['b'], c['cin'], c['h'], c['h'])).to(dev())
+    w = synth.tensor(c['name'] + '/w', (c['b'], 512)).to(dev())
+    ref = g[c['name'] + '/out']
+    with torch.no_grad():
+        y = m(x, w)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+    # the differentiable composite used for the backward graph is the same function
+    from op import modconv
+    with torch.no_grad():
+        s = m.modulation(w)
+        yc = modconv.modconv_composite(x, m.weight, s, c['demod'], 1 if c['up'] else 0, m.scale)
+        if c['up']:
+            yc = m.blur(yc)
+    np.testing.assert_allclose(yc.cpu().numpy(), ref, **_tol(ref, 5e-5))
+
+
+@pytest.mark.parametrize('cfg', [
+    # (b, cin, cout, h, w, mode)  — every tile configuration: cout >=96 / >=48 / <48, widths 4..>32, sample packing
+    (5, 12, 130, 4, 4, 0), (5, 12, 130, 4, 4, 1), (3, 7, 64, 8, 8, 0), (3, 7, 64, 8, 8, 1),
+    (2, 33, 32, 16, 16, 0), (2, 33, 32, 16, 16, 1), (1, 16, 100, 33, 35, 0), (1, 16, 100, 33, 35, 1),
+    (2, 8, 50, 70, 40, 0), (2, 8, 50, 70, 40, 1), (1, 40, 20, 64, 64, 0), (1, 40, 20, 64, 64, 1),
+    (9, 5, 3, 5, 3, 0), (9, 5, 3, 5, 3, 1),
+])
+@pytest.mark.parametrize('demod', [True, False])
+def test_modconv_kernel_vs_c_oracle(cfg, demod):
+    from op import _native
+    from oracle import c_oracle
+    b, cin, cout, h, w, mode = cfg
+    x = synth.tensor(f'mck/{cfg}/x', (b, cin, h, w))
+    wgt = synth.tensor(f'mck/{cfg}/w', (cout, cin, 3, 3))
+    s = synth.tensor(f'mck/{cfg}/s', (b, cin), shift=1.0, scale=0.5)
+    scale = 1.0 / np.sqrt(cin * 9)
+    ref = c_oracle.modulated_conv2d(x.numpy(), wgt.numpy(), s.numpy(), mode=mode, demodulate=demod)
+    xd, wd, sd = x.to(dev()), wgt.to(dev()), s.to(dev())
+    wt = _native.modconv_weight_prep(wd, scale)
+    np.testing.assert_allclose(wt.cpu().numpy(), (wgt.numpy() * np.float32(scale)).reshape(cout, cin, 9).transpose(1, 2, 0),
+                               atol=0, rtol=0)
+    dm = _native.modconv_demod(wd, sd, scale) if demod else None
+    if demod:
+        dref = 1.0 / np.sqrt(((np.float64(scale) * wgt.numpy()[None].astype(np.float64) *
+                               s.numpy()[:, None, :, None, None]) ** 2).sum(axis=(2, 3, 4)) + 1e-8)
+        np.testing.assert_allclose(dm.cpu().numpy(), dref, rtol=2e-6, atol=0)
+    y = _native.modconv2d(xd, wt, sd, dm, mode)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+
+
+@pytest.mark.parametrize('c', cases.STYLEDCONV_CASES, ids=lambda c: c['name'])
+def test_styled_conv_golden_fused_and_unfused(c, golden):
+    import stylegan2
+    g = golden('modules')
+    m = _load(stylegan2.StyledConv(c['cin'], c['cout'], 3, 512, upsample=c['up']), 'generator', 2)
+    oh = c['h'] * 2 if c['up'] else c['h']
+    x = synth.tensor(c['name'] + '/x', (c['b'], c['cin'], c['h'], c['h'])).to(dev())
+    w = synth.tensor(c['name'] + '/w', (c['b'], 512)).to(dev())
+    nz = synth.tensor(c['name'] + '/noise', (c['nb'], 1, oh, oh)).to(dev())
+    ref = g[c['name'] + '/out']
+    with torch.no_grad():
+        y_fused = m(x, w, noise=nz)                      # conv-epilogue / one-pass fused path
+    y_graph = m(x, w, noise=nz)                          # autograd path: three separate ops
+    np.testing.assert_allclose(y_fused.cpu().numpy(), ref, **_tol(ref))
+    np.testing.assert_allclose(y_graph.detach().cpu().numpy(), ref, **_tol(ref))
+    torch.testing.assert_close(y_fused, y_graph.detach(), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize('c', cases.TORGB_CASES, ids=lambda c: c['name'])
+def test_to_rgb_golden(c, golden):
+    import stylegan2
+    g = golden('modules')
+    m = _load(stylegan2.ToRGB(c['cin'], 512, upsample=c['skip']), 'generator', 3)
+    x = synth.tensor(c['name'] + '/x', (c['b'], c['cin'], c['h'], c['h'])).to(dev())
+    w = synth.tensor(c['name'] + '/w', (c['b'], 512)).to(dev())
+    skip = synth.tensor(c['name'] + '/skip', (c['b'], 3, c['h'] // 2, c['h'] // 2)).to(dev()) if c['skip'] else None
+    ref = g[c['name'] + '/out']
+    with torch.no_grad():
+        y = m(x, w, skip)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+
+
+def test_torgb_kernel_vs_c_oracle_ragged():
+    from op import _native
+    from oracle import c_oracle
+    for (b, cin, h, w) in ((2, 37, 5, 7), (1, 512, 4, 4), (3, 64, 32, 32), (1, 32, 128, 128)):
+        x = synth.tensor(f'rgbk/{cin}{h}/x', (b, cin, h, w))
+        wgt = synth.tensor(f'rgbk/{cin}{h}/w', (3, cin))
+        s = synth.tensor(f'rgbk/{cin}{h}/s', (b, cin), shift=1.0, scale=0.5)
+        bias = synth.tensor(f'rgbk/{cin}{h}/b', (3,))
+        skip = synth.tensor(f'rgbk/{cin}{h}/k', (b, 3, h, w))
+        ref = c_oracle.to_rgb(x.numpy(), wgt.numpy(), s.numpy(), bias.numpy(), skip.numpy())
+        y = _native.torgb(x.to(dev()), wgt.to(dev()), s.to(dev()), bias.to(dev()), skip.to(dev()), 1.0 / np.sqrt(cin))
+        np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+
+
+def test_modconv_gradients_match_reference_formulation():
+    """First and second derivatives through the HIP forward (recompute-composite backward) equal autograd through
+    the CPU oracle's weight-modulated grouped conv (the reference's formulation)."""
+    import stylegan2
+    from oracle import torch_oracle as T
+    for up in (False, True):
+        m = _load(stylegan2.StyledConv(6, 10, 3, 512, upsample=up), 'generator', 11)
+        sd = {'m.' + k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+        x = synth.tensor(f'mcg/{up}/x', (2, 6, 5, 5))
+        w = synth.tensor(f'mcg/{up}/w', (2, 512))
+        oh = 10 if up else 5
+        nz = synth.tensor(f'mcg/{up}/n', (2, 1, oh, oh))
+        xo, wo = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        yo = T.styled_conv(sd, 'm', xo, wo, nz.double(), up)
+        go = synth.tensor(f'mcg/{up}/go', yo.shape)
+        gxo, gwo = torch.autograd.grad(yo, (xo, wo), go.double(), create_graph=True)
+        pen_o = gxo.pow(2).sum() + gwo.pow(2).sum()
+        ggo, = torch.autograd.grad(pen_o, wo)
+        xd, wd = x.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+        yd = m(xd, wd, noise=nz.to(dev()))
+        np.testing.assert_allclose(yd.detach().cpu().numpy(), yo.detach().numpy(), **_tol(yo.detach().numpy()))
+        gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.to(dev()), create_graph=True)
+        np.testing.assert_allclose(gxd.detach().cpu().numpy(), gxo.detach().numpy(), **_tol(gxo.detach().numpy(), 1e-4))
+        np.testing.assert_allclose(gwd.detach().cpu().numpy(), gwo.detach().numpy(), **_tol(gwo.detach().numpy(), 1e-4))
+        pen_d = gxd.pow(2).sum() + gwd.pow(2).sum()
+        ggd, = torch.autograd.grad(pen_d, wd)
+        np.testing.assert_allclose(ggd.cpu().numpy(), ggo.numpy(), **_tol(ggo.numpy(), 5e-4))

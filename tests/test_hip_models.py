@@ -1,0 +1,200 @@
+"""GPU parity tests at model level: Generator / 3-encoder forward / Discriminator on the HIP path vs the golden
+vectors captured from the reference, and gradients (first order, R1- and path-length-style second order) vs
+autograd through the CPU oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def _load(module, kind, seed):
+    module.load_state_dict(synth.state_dict(kind, module.state_dict(), seed=seed))
+    return module.to(dev()).eval()
+
+
+def _img_close(img, g, name, stride, rel=1e-4):
+    a = img.detach().float().cpu().numpy()
+    ref = g[name + '/sub']
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(a[..., ::stride, ::stride], ref, atol=rel * scale, rtol=rel)
+    st = g[name + '/stats']
+    a64 = a.astype(np.float64)
+    np.testing.assert_allclose([a64.mean(), np.abs(a64).mean()], st[:2], atol=rel * scale, rtol=rel)
+    np.testing.assert_allclose((a64 * a64).sum(), st[4], rtol=10 * rel)
+
+
+@pytest.mark.parametrize('c', cases.GENERATOR_CASES, ids=lambda c: c['name'])
+def test_generator_golden(c, golden):
+    """End-to-end image tolerance 1e-4 of the image's max-abs."""
+    import stylegan2
+    g = golden('generator')
+    G = _load(stylegan2.Generator(c['size'], 512, c['n_mlp'], generator_net_shape=c['shape']), 'generator', 4)
+    with torch.no_grad():
+        if c['mode'] == 'latent':
+            cin0 = c['shape'][0] if c['shape'] else 512
+            lat = synth.tensor(c['name'] + '/latent', (c['b'], G.n_latent, 512)).to(dev())
+            tsr = synth.tensor(c['name'] + '/tsr', (c['b'], cin0, 4, 4)).to(dev())
+            img = G(None, latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True,
+                    external_input_tensor=tsr, randomize_noise=False)
+        else:
+            img = G([synth.tensor(c['name'] + '/z', (c['b'], 512)).to(dev())], randomize_noise=False)
+    _img_close(img, g, c['name'], c['stride'])
+
+
+def test_generator_graph_path_equals_fused_path(golden):
+    """With autograd enabled StyledConv runs conv / noise / act as three ops; the image must not change."""
+    import stylegan2
+    c = cases.GENERATOR_CASES[0]
+    G = _load(stylegan2.Generator(c['size'], 512, c['n_mlp'], generator_net_shape=c['shape']), 'generator', 4)
+    lat = synth.tensor(c['name'] + '/latent', (c['b'], G.n_latent, 512)).to(dev())
+    tsr = synth.tensor(c['name'] + '/tsr', (c['b'], 16, 4, 4)).to(dev())
+    kw = dict(latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True, external_input_tensor=tsr,
+              randomize_noise=False)
+    with torch.no_grad():
+        a = G(None, **kw)
+    b = G(None, **kw)
+    _img_close(b, golden('generator'), c['name'], 1)
+    torch.testing.assert_close(a, b.detach(), atol=1e-5, rtol=1e-5)
+    rgbs, scalars = G(None, return_rgb_list=True, return_style_scalars=True, **kw)
+    assert len(rgbs) == 5 and len(scalars) == G.num_layers + 1
+    torch.testing.assert_close(rgbs[-1].detach(), a, atol=1e-5, rtol=1e-5)
+
+
+def _encoders(n_styles):
+    import resnet_encoder
+    from psp_encoder_model.encoders import psp_encoders
+    e_tsr = _load(resnet_encoder.resnet18(tensor_encoding=True, tensor_transform=False), 'resnet', 5)
+    e_w = _load(resnet_encoder.resnet18(tensor_encoding=False, tensor_transform=False), 'resnet', 6)
+    e_wp = _load(psp_encoders.GradualStyleEncoder(18, 'ir_se', types.SimpleNamespace(input_nc=3, n_styles=n_styles)),
+                 'psp', 7)
+    return e_tsr, e_w, e_wp
+
+
+class _PinNoise(torch.nn.Module):
+    """The reference's Forward_Inference_3_Encoder never passes noise; the golden run pinned
+    randomize_noise=False the same way."""
+
+    def __init__(self, g):
+        super().__init__()
+        self.module = g
+
+    def forward(self, **kw):
+        return self.module(randomize_noise=False, **kw)
+
+
+@pytest.mark.parametrize('c', cases.E2E_CASES, ids=lambda c: c['name'])
+def test_forward_inference_3_encoder_golden(c, golden):
+    """(photo, render) -> image through encoders (MIOpen) + Generator (HIP kernels) vs the reference."""
+    import stylegan2
+    from Util.network_util import Forward_Inference_3_Encoder
+    g = golden('e2e')
+    n_latent = int(np.log2(c['size'])) * 2 - 2
+    e_tsr, e_w, e_wp = _encoders(n_latent)
+    G = _load(stylegan2.Generator(c['size'], 512, 8), 'generator', 4)
+    p = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform').to(dev())
+    r = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform').to(dev())
+    with torch.no_grad():
+        np.testing.assert_allclose(e_tsr(p).cpu().numpy(), g[c['name'] + '/e_tsr'], atol=5e-4, rtol=5e-4)
+        np.testing.assert_allclose(e_w(r).cpu().numpy(), g[c['name'] + '/e_w'], atol=5e-4, rtol=5e-4)
+        ref_wp = g[c['name'] + '/e_wplus']
+        np.testing.assert_allclose(e_wp(p).cpu().numpy(), ref_wp, atol=5e-4 * np.abs(ref_wp).max(), rtol=5e-4)
+        img = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, _PinNoise(G), tsr_encode=c['tsr_encode'],
+                                          sliced_layer=c['sliced_layer'], use_tanh=c['use_tanh'])
+    # encoders run on MIOpen (different summation order than the CPU reference): 1e-3 of max-abs end to end
+    _img_close(img, g, c['name'], c['stride'], rel=1e-3)
+
+
+@pytest.mark.parametrize('c', cases.DISCRIMINATOR_CASES, ids=lambda c: c['name'])
+def test_discriminator_golden(c, golden):
+    import stylegan2
+    g = golden('discriminator')
+    D = _load(stylegan2.Discriminator(c['size']), 'discriminator', 8)
+    x = synth.tensor(c['name'] + '/x', (c['b'], 3, c['size'], c['size']), dist='uniform').to(dev())
+    with torch.no_grad():
+        y = D(x)
+    ref = g[c['name'] + '/out']
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=1e-3 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+
+
+def test_generator_gradients_and_path_length_vs_oracle():
+    """Narrow Generator(32): d(image)/d(latent, tensor, weights) and the in-forward path-length regulariser
+    (second order, stylegan2.py:683-688) vs float64 autograd through the CPU oracle."""
+    import math
+    import stylegan2
+    from oracle import torch_oracle as T
+    shape = [8, 8, 8, 8, 8, 8, 6, 6]
+    G = _load(stylegan2.Generator(32, 512, 1, generator_net_shape=shape), 'generator', 12)
+    sd64 = {k: v.detach().cpu().double() for k, v in G.state_dict().items()}
+    lat = synth.tensor('gg/lat', (2, G.n_latent, 512))
+    tsr = synth.tensor('gg/tsr', (2, 8, 4, 4))
+    go = synth.tensor('gg/go', (2, 3, 32, 32))
+    # oracle
+    lo, to = lat.double().requires_grad_(True), tsr.double().requires_grad_(True)
+    wkey = 'convs.1.conv.weight'
+    sd64[wkey].requires_grad_(True)
+    img_o = T.generator_forward(sd64, 32, lo, external_input_tensor=to, noise='buffers')
+    glo, gto, gwo = torch.autograd.grad(img_o, (lo, to, sd64[wkey]), go.double(), create_graph=True)
+    probe = synth.tensor('gg/probe', (2, 3, 32, 32)).double() / math.sqrt(32 * 32)
+    gpl_o, = torch.autograd.grad((img_o * probe).sum(), lo, create_graph=True)
+    pl_o = torch.sqrt(gpl_o.pow(2).sum(2).mean(1))
+    gpl2_o, = torch.autograd.grad(pl_o.sum(), lo)
+    # HIP
+    ld, td = lat.to(dev()).requires_grad_(True), tsr.to(dev()).requires_grad_(True)
+    img_d = G(None, latent_styles=[ld], input_is_latent=True, use_external_input_tensor=True, external_input_tensor=td,
+              randomize_noise=False)
+    wd = dict(G.named_parameters())[wkey]
+    gld, gtd, gwd = torch.autograd.grad(img_d, (ld, td, wd), go.to(dev()), create_graph=True)
+
+    def close(a, b, k):
+        b = b.detach().numpy()
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b, atol=k * max(1e-6, float(np.abs(b).max())), rtol=k)
+
+    close(img_d, img_o, 1e-4)
+    close(gld, glo, 1e-3)
+    close(gtd, gto, 1e-3)
+    close(gwd, gwo, 1e-3)
+    gpl_d, = torch.autograd.grad((img_d * probe.float().to(dev())).sum(), ld, create_graph=True)
+    pl_d = torch.sqrt(gpl_d.pow(2).sum(2).mean(1))
+    gpl2_d, = torch.autograd.grad(pl_d.sum(), ld)
+    close(pl_d, pl_o, 1e-3)
+    close(gpl2_d, gpl2_o, 5e-3)
+    # and the PPL_regularize=True return signature
+    out = G(None, latent_styles=[ld], input_is_latent=True, use_external_input_tensor=True, external_input_tensor=td,
+            randomize_noise=False, PPL_regularize=True)
+    assert isinstance(out, tuple) and tuple(out[1].shape) == (2,)
+
+
+def test_discriminator_r1_penalty_vs_oracle():
+    """R1 (Util/training_util.py:46-52): grad of D(real) w.r.t. the image with create_graph, then backward —
+    double-backward through upfirdn2d and fused_leaky_relu on the HIP path."""
+    import stylegan2
+    from oracle import torch_oracle as T
+    D = _load(stylegan2.Discriminator(16), 'discriminator', 13)
+    sd64 = {k: v.detach().cpu().double() for k, v in D.state_dict().items()}
+    x = synth.tensor('r1/x', (4, 3, 16, 16), dist='uniform')
+    wkey = 'convs.1.conv2.1.weight'
+    sd64[wkey].requires_grad_(True)
+    xo = x.double().requires_grad_(True)
+    yo = T.discriminator_forward(sd64, xo, 16)
+    gxo, = torch.autograd.grad(yo.sum(), xo, create_graph=True)
+    r1_o = gxo.pow(2).reshape(4, -1).sum(1).mean()
+    gw_o, = torch.autograd.grad(r1_o, sd64[wkey])
+    xd = x.to(dev()).requires_grad_(True)
+    yd = D(xd)
+    gxd, = torch.autograd.grad(yd.sum(), xd, create_graph=True)
+    r1_d = gxd.pow(2).reshape(4, -1).sum(1).mean()
+    gw_d, = torch.autograd.grad(r1_d, dict(D.named_parameters())[wkey])
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yo.detach().numpy(), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(r1_d.item(), r1_o.item(), rtol=1e-3)
+    ref = gw_o.numpy()
+    np.testing.assert_allclose(gw_d.cpu().numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=2e-3)

@@ -1,0 +1,224 @@
+"""GPU parity tests for upfirdn2d and fused_bias_act: HIP path (through the C-ABI) vs the golden vectors captured
+from the reference and vs the CPU oracle, plus size-independent properties at BASELINE's full sizes."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+
+pytestmark = pytest.mark.gpu
+OP_TOL = dict(atol=1e-5, rtol=1e-5)   # SURVEY.md §8c / BASELINE.md §4: per-op fp32 tolerance
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def _run_ufd(x, k, c, force_path=-1):
+    from op import _native
+    n, ch, h, w = x.shape
+    p0, p1 = c['pad']
+    y = _native.upfirdn2d(x.reshape(-1, h, w, 1), k, c['up'], c['up'], c['down'], c['down'], p0, p1, p0, p1, force_path)
+    return y.view(n, ch, y.shape[1], y.shape[2])
+
+
+@pytest.mark.parametrize('c', cases.UPFIRDN2D_CASES, ids=lambda c: c['name'])
+def test_upfirdn2d_golden(c, golden):
+    from op import upfirdn2d, _native
+    g = golden('upfirdn2d')
+    x = synth.tensor(c['name'] + '/x', c['shape']).to(dev())
+    k = cases.make_fir(c['kernel']).to(dev())
+    ref = g[c['name'] + '/out']
+    y = upfirdn2d(x, k, up=c['up'], down=c['down'], pad=tuple(c['pad']))
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **OP_TOL)
+    # every kernel path that accepts these arguments gives the same answer
+    for path in (0, 1, 2, 3, 5):
+        try:
+            yp = _run_ufd(x, k, c, path)
+        except RuntimeError as e:
+            assert 'unsupported' in str(e)
+            continue
+        np.testing.assert_allclose(yp.cpu().numpy(), ref, err_msg=f'path {path}', **OP_TOL)
+    # float64 through the generic kernel
+    y64 = upfirdn2d(x.double(), k.double(), up=c['up'], down=c['down'], pad=tuple(c['pad']))
+    np.testing.assert_allclose(y64.cpu().numpy(), ref, atol=2e-5, rtol=2e-5)
+    # float16: storage rounding only (fp32 accumulation)
+    y16 = upfirdn2d(x.half(), k.half(), up=c['up'], down=c['down'], pad=tuple(c['pad']))
+    np.testing.assert_allclose(y16.float().cpu().numpy(), ref, atol=2e-2 * max(1.0, np.abs(ref).max()), rtol=2e-2)
+
+
+@pytest.mark.parametrize('c', [c for c in cases.UPFIRDN2D_CASES if c['grad']], ids=lambda c: c['name'])
+def test_upfirdn2d_gradients_golden(c, golden):
+    from op import upfirdn2d
+    g = golden('upfirdn2d')
+    x = synth.tensor(c['name'] + '/x', c['shape']).to(dev()).requires_grad_(True)
+    k = cases.make_fir(c['kernel']).to(dev())
+    y = upfirdn2d(x, k, up=c['up'], down=c['down'], pad=tuple(c['pad']))
+    go = synth.tensor(c['name'] + '/go', y.shape).to(dev()).requires_grad_(True)
+    gi, = torch.autograd.grad(y, x, go, create_graph=True)
+    np.testing.assert_allclose(gi.detach().cpu().numpy(), g[c['name'] + '/grad_input'], **OP_TOL)
+    ggi = synth.tensor(c['name'] + '/ggi', x.shape).to(dev())
+    gg, = torch.autograd.grad(gi, go, ggi)
+    np.testing.assert_allclose(gg.cpu().numpy(), g[c['name'] + '/gradgrad_out'], **OP_TOL)
+
+
+def test_upfirdn2d_gradcheck_f64():
+    from op import upfirdn2d
+    k = cases.make_fir(('rand', 4, 4, 21)).double().to(dev())
+    for up, down, pad in ((1, 1, (1, 1)), (2, 1, (2, 1)), (1, 2, (1, 1))):
+        x = synth.tensor(f'gc/{up}{down}', (1, 2, 6, 6), dtype=torch.float64).to(dev()).requires_grad_(True)
+        assert torch.autograd.gradcheck(lambda t: upfirdn2d(t, k, up=up, down=down, pad=pad), (x,))
+        assert torch.autograd.gradgradcheck(lambda t: upfirdn2d(t, k, up=up, down=down, pad=pad), (x,))
+
+
+@pytest.mark.parametrize('shape,kernel,pad', [
+    ((3, 5, 131, 257), ('rand', 4, 4, 31), (1, 1)),      # ragged: partial strips, odd widths, VEC=4
+    ((2, 3, 100, 100), ('rand', 4, 4, 32), (2, 2)),      # VEC=2 strips, bigger output than input
+    ((1, 4, 70, 67), ('rand', 3, 4, 33), (1, 2)),        # VEC=1, non-square taps
+    ((1, 2, 513, 513), 'blur4', (1, 1)),
+    ((2, 2, 300, 1025), ('rand', 4, 4, 34), (1, 1)),     # 1025-wide rows: never 16-byte aligned
+    ((1, 1, 1024, 1024), ('rand', 4, 4, 35), (2, 2)),    # grad of the headline blur: 1025x1025 out
+])
+def test_upfirdn2d_rowmarch_vs_c_oracle(shape, kernel, pad):
+    from oracle import c_oracle
+    c = dict(up=1, down=1, pad=pad)
+    x = synth.tensor(f'rm/{shape}', shape)
+    k = cases.make_fir(kernel)
+    n, ch, h, w = shape
+    ref = c_oracle.upfirdn2d(x.reshape(n * ch, h, w, 1).numpy(), k.numpy(), (1, 1), (1, 1), (pad[0], pad[1], pad[0], pad[1]))
+    y1 = _run_ufd(x.to(dev()), k.to(dev()), c, 1)
+    y0 = _run_ufd(x.to(dev()), k.to(dev()), c, 0)
+    np.testing.assert_allclose(y1.cpu().numpy().reshape(ref.shape), ref, **OP_TOL)
+    np.testing.assert_allclose(y0.cpu().numpy().reshape(ref.shape), ref, **OP_TOL)
+
+
+def test_upfirdn2d_many_planes_and_minor():
+    """major > 16384 (the reference's loop_major path, op/upfirdn2d_kernel.cu:296) and minor > 1 (generic kernel)."""
+    from op import _native
+    from oracle import c_oracle
+    k = cases.make_fir(('rand', 4, 4, 41))
+    x = synth.tensor('many/x', (20000, 9, 9, 1))
+    ref = c_oracle.upfirdn2d(x.numpy(), k.numpy(), (1, 1), (1, 1), (1, 1, 1, 1))
+    y = _native.upfirdn2d(x.to(dev()), k.to(dev()), 1, 1, 1, 1, 1, 1, 1, 1)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **OP_TOL)
+    xm = synth.tensor('minor/x', (3, 10, 11, 5))
+    refm = c_oracle.upfirdn2d(xm.numpy(), k.numpy(), (2, 1), (1, 2), (2, 1, 1, 1))
+    ym = _native.upfirdn2d(xm.to(dev()), k.to(dev()), 2, 1, 1, 2, 2, 1, 1, 1)
+    np.testing.assert_allclose(ym.cpu().numpy(), refm, **OP_TOL)
+
+
+def test_upfirdn2d_headline_properties():
+    """BASELINE headline call [B*32,1025,1025] -> [B*32,1024,1024] at B=8 (2.15 GB): too big for the CPU oracle
+    in seconds, so check (a) sampled planes against the C oracle, (b) linearity, (c) DC gain = sum(taps),
+    (d) the adjoint identity <blur(x), g> == <x, blur^T(g)> that the backward relies on."""
+    from op import upfirdn2d, _native
+    from oracle import c_oracle
+    d = dev()
+    k = cases.make_fir('blur4').to(d)
+    gen = torch.Generator(device=d).manual_seed(1234)
+    x = torch.randn(8, 32, 1025, 1025, device=d, generator=gen)
+    y = upfirdn2d(x, k, pad=(1, 1))
+    assert tuple(y.shape) == (8, 32, 1024, 1024)
+    assert _native.lib().fmgan_upfirdn2d_select(0, 256, 1025, 1025, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) == 1
+    for (b, c) in ((0, 0), (3, 17), (7, 31)):
+        ref = c_oracle.upfirdn2d(x[b, c].cpu().numpy().reshape(1, 1025, 1025, 1), k.cpu().numpy(), (1, 1), (1, 1), (1, 1, 1, 1))
+        np.testing.assert_allclose(y[b, c].cpu().numpy(), ref.reshape(1024, 1024), **OP_TOL)
+    x2 = torch.randn(1, 32, 1025, 1025, device=d, generator=gen)
+    lin = upfirdn2d(2.0 * x[:1] - 0.5 * x2, k, pad=(1, 1))
+    torch.testing.assert_close(lin, 2.0 * y[:1] - 0.5 * upfirdn2d(x2, k, pad=(1, 1)), atol=2e-5, rtol=1e-5)
+    ones = torch.ones(1, 1, 1025, 1025, device=d)
+    dc = upfirdn2d(ones, k, pad=(1, 1))
+    torch.testing.assert_close(dc[0, 0, 2:-2, 2:-2], torch.full((1020, 1020), 4.0, device=d), atol=1e-5, rtol=1e-6)
+    g = torch.randn(1, 32, 1024, 1024, device=d, generator=gen)
+    xa = x[:1].clone().double().requires_grad_(True)
+    ya = upfirdn2d(xa, k.double(), pad=(1, 1))
+    gi, = torch.autograd.grad(ya, xa, g.double())
+    lhs = (ya.detach() * g.double()).sum()
+    rhs = (xa.detach() * gi).sum()
+    assert abs((lhs - rhs) / lhs) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------ fused_bias_act
+@pytest.mark.parametrize('c', cases.FUSED_ACT_CASES, ids=lambda c: c['name'])
+def test_fused_act_golden(c, golden):
+    from op import fused_leaky_relu
+    g = golden('fused_act')
+    x, b = cases.fused_act_inputs(c)
+    x = x.to(dev()).requires_grad_(True)
+    b = b.to(dev()).requires_grad_(True) if b is not None else None
+    y = fused_leaky_relu(x, b)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[c['name'] + '/out'], atol=1e-6, rtol=1e-6)
+    go = synth.tensor(c['name'] + '/go', y.shape).to(dev()).requires_grad_(True)
+    ins = [x] + ([b] if b is not None else [])
+    grads = torch.autograd.grad(y, ins, go, create_graph=True)
+    np.testing.assert_allclose(grads[0].detach().cpu().numpy(), g[c['name'] + '/grad_input'], atol=1e-6, rtol=1e-6)
+    if b is not None:
+        np.testing.assert_allclose(grads[1].detach().cpu().numpy(), g[c['name'] + '/grad_bias'], atol=2e-5, rtol=2e-5)
+    ggi = synth.tensor(c['name'] + '/ggi', x.shape).to(dev())
+    gg, = torch.autograd.grad(grads[0], go, ggi)
+    np.testing.assert_allclose(gg.cpu().numpy(), g[c['name'] + '/gradgrad_out'], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize('act,grad', [(3, 0), (3, 1), (3, 2), (1, 0), (1, 1), (1, 2)])
+@pytest.mark.parametrize('shape', [(2, 6, 8, 8), (3, 5, 7, 3), (2, 32, 64, 64), (4, 512), (1, 3, 1, 1)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64, torch.float16])
+def test_fused_bias_act_all_modes_vs_c_oracle(act, grad, shape, dtype):
+    """Every act*10+grad code of the reference kernel (op/fused_bias_act_kernel.cu:36-45), a non-default alpha
+    (the CUDA kernel honours it), with and without bias / refer — bit-exact in fp32."""
+    from op import _native
+    from oracle import c_oracle
+    x = synth.tensor(f'fba/{shape}/x', shape)
+    b = synth.tensor(f'fba/{shape}/b', (shape[1],))
+    r = synth.tensor(f'fba/{shape}/r', shape)
+    x.view(-1)[::7] = 0.0
+    r.view(-1)[::5] = 0.0
+    for use_b, use_r in ((True, True), (False, True), (True, False), (False, False)):
+        xn = x.numpy().astype(np.float64 if dtype == torch.float64 else np.float32)
+        if dtype == torch.float16:
+            xn = x.half().float().numpy()
+        bn = None if not use_b else (b.half().float() if dtype == torch.float16 else b).numpy().astype(xn.dtype)
+        rn = None if not use_r else (r.half().float() if dtype == torch.float16 else r).numpy().astype(xn.dtype)
+        # the reference passes alpha/scale as C++ floats converted to scalar_t (fused_bias_act_kernel.cu:52-53,79-89)
+        a32, s32 = float(np.float32(0.3)), float(np.float32(1.7))
+        ref = c_oracle.fused_bias_act(xn, bn, rn, act, grad, a32, s32)
+        e = torch.empty(0, device=dev(), dtype=dtype)
+        y = _native.fused_bias_act(x.to(dev(), dtype), b.to(dev(), dtype) if use_b else e,
+                                   r.to(dev(), dtype) if use_r else e, act, grad, 0.3, 1.7)
+        if dtype == torch.float16:
+            np.testing.assert_allclose(y.float().cpu().numpy(), ref, atol=2e-3 * max(1, np.abs(ref).max()), rtol=2e-3)
+        else:
+            np.testing.assert_array_equal(y.cpu().numpy(), ref)
+
+
+def test_fused_act_full_size_bit_exact():
+    """[8,32,1024,1024] (1.07 GB), BASELINE cfg4's largest activation: bit-exact against the C oracle on sampled
+    planes, idempotence of the sign pattern, and grad_bias == plane sums."""
+    from op import fused_leaky_relu, _native
+    from oracle import c_oracle
+    d = dev()
+    gen = torch.Generator(device=d).manual_seed(7)
+    x = torch.randn(8, 32, 1024, 1024, device=d, generator=gen)
+    b = torch.randn(32, device=d, generator=gen)
+    y = fused_leaky_relu(x, b)
+    for (n, c) in ((0, 0), (5, 13), (7, 31)):
+        ref = c_oracle.fused_bias_act(x[n:n + 1, c:c + 1].cpu().numpy(), b[c:c + 1].cpu().numpy(), None, 3, 0, 0.2, 2 ** 0.5)
+        np.testing.assert_array_equal(y[n:n + 1, c:c + 1].cpu().numpy(), ref)
+    assert torch.equal(y > 0, (x + b.view(1, -1, 1, 1)) > 0)
+    e = x.new_empty(0)
+    gi = _native.fused_bias_act(torch.ones_like(x), e, y, 3, 1, 0.2, 2 ** 0.5)
+    expect = torch.where(y > 0, torch.tensor(2 ** 0.5, device=d), torch.tensor(0.2 * 2 ** 0.5, device=d))
+    torch.testing.assert_close(gi, expect, atol=0, rtol=0)
+
+
+def test_noise_bias_act_matches_unfused_bitwise():
+    from op import _native, fused_leaky_relu
+    d = dev()
+    for (b, c, h, nb) in ((2, 16, 8, 2), (3, 24, 16, 1), (1, 5, 7, 1), (2, 32, 64, 2)):
+        x = synth.tensor(f'nba/{b}{c}{h}/x', (b, c, h, h)).to(d)
+        nz = synth.tensor(f'nba/{b}{c}{h}/n', (nb, 1, h, h)).to(d)
+        nw = torch.tensor([0.37], device=d)
+        bias = synth.tensor(f'nba/{b}{c}{h}/b', (c,)).to(d)
+        ref = fused_leaky_relu(x + nw * nz, bias)
+        y = _native.noise_bias_act(x, nz, nw, bias, 0.2, 2 ** 0.5)
+        assert torch.equal(y, ref)
