@@ -84,23 +84,45 @@ __global__ __launch_bounds__(256) void modconv_weight_prep_f32(const float* __re
 struct MCParams {
   const float* in; const float* wt; const float* style; const float* demod; float* out;
   int batch, cin, cout, h, w, oh, ow;
-  int th, nb;                        // tile rows per sample, samples per tile
-  int tiles_x, tiles_y, tiles_b, o_tiles;
+  // Position grid = up to 3 rectangular segments tiled independently but launched together (mode 1: the h x w
+  // quad grid plus the last output row and the last output column; mode 0: one segment h x w).
+  struct Seg {
+    int m_off, n_off, gh, gw;        // sub-grid origin and size (positions)
+    int th, nb, tw_log2;             // tile rows per sample, samples per tile, log2(tile width)
+    int tiles_x, tiles_y, tiles_b;
+    unsigned block_end;              // first logical block id after this segment
+  } seg[3];
+  int nseg, o_tiles;
+  int ksplit, cin_per_split;         // split-K over input channels (tiny layers); partials go to `ws`
+  float* ws;
   const float* noise; const float* noise_weight; const float* bias;
   int noise_batch, fuse_act; float alpha, act_scale;
 };
 
 constexpr int MC_KC = 8;  // input channels per LDS chunk
 
-template <int MODE, int RM, int RN, int WM, int WN, int TW>
-__global__ __launch_bounds__(256) void modconv_mfma_f32(const MCParams p) {
+// demod scale + optional StyledConv epilogue (stylegan2.py:371-373) — shared by the conv epilogue and the split-K finish
+__device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float nw, int b, int o, int pix) {
+  if (p.demod) v *= p.demod[(long long)b * p.cout + o];
+  if (p.fuse_act) {
+    const float n = p.noise ? p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * p.oh * p.ow + pix] : 0.f;
+    const float bv = p.bias ? p.bias[o] : 0.f;
+    v = __fadd_rn(__fadd_rn(v, __fmul_rn(nw, n)), bv);
+    v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
+  }
+  return v;
+}
+
+// MODE 0: plain 3x3, one output pixel per position, 9 taps.
+// MODE 1: transposed stride-2 3x3. Position (m,n) owns the 2x2 output quad (2m+py, 2n+px); its four phases
+//         use 4+2+2+1 = 9 taps of the same staged weights and only 4 distinct input offsets:
+//         out[2m+py, 2n+px] += w[ky][kx] * in[m - ky/2, n - kx/2],  ky = py (mod 2), kx = px (mod 2).
+template <int MODE, int RM, int RNP, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   constexpr int KC = MC_KC;
   constexpr int BM = 32 * RM * WM;
-  constexpr int NPX = MODE == 1 ? 2 : 1;
-  constexpr int RNP = RN / NPX;  // 32-position groups per wave
-  constexpr int PWP = TW + 2;
+  constexpr int NPH = MODE == 1 ? 4 : 1;   // output phases per position
   static_assert(WM * WN == 4, "4 waves per block");
-  static_assert(RN % NPX == 0, "RN must cover both column phases");
   extern __shared__ float smem[];
   float* Ws = smem;                 // [KC][9][BM]
   float* Xs = smem + KC * 9 * BM;   // [nb][KC][PH][PWP]
@@ -109,15 +131,22 @@ __global__ __launch_bounds__(256) void modconv_mfma_f32(const MCParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, khalf = lane >> 5;
 
-  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  int si = 0;
+  while (si + 1 < p.nseg && lb >= p.seg[si].block_end) ++si;
+  if (si > 0) lb -= p.seg[si - 1].block_end;
+  const int seg_th = p.seg[si].th, seg_nb = p.seg[si].nb, tw_log2 = p.seg[si].tw_log2;
+  const int seg_m_end = p.seg[si].m_off + p.seg[si].gh, seg_n_end = p.seg[si].n_off + p.seg[si].gw;
+  const int TW = 1 << tw_log2, PWP = TW + 2;
   const int o_tile = lb % p.o_tiles;
   unsigned pt = lb / p.o_tiles;
-  const int tx_i = pt % p.tiles_x; pt /= p.tiles_x;
-  const int ty_i = pt % p.tiles_y;
-  const int tb_i = pt / p.tiles_y;
-  const int py = MODE == 1 ? (int)blockIdx.y : 0;
-  const int o0 = o_tile * BM, x0 = tx_i * TW, y0 = ty_i * p.th, b0 = tb_i * p.nb;
-  const int PH = p.th + 2;
+  const int tx_i = pt % p.seg[si].tiles_x; pt /= p.seg[si].tiles_x;
+  const int ty_i = pt % p.seg[si].tiles_y;
+  const int tb_i = pt / p.seg[si].tiles_y;
+  const int ks = blockIdx.y;
+  const int o0 = o_tile * BM, b0 = tb_i * seg_nb;
+  const int x0 = p.seg[si].n_off + tx_i * TW, y0 = p.seg[si].m_off + ty_i * seg_th;   // first position of the tile
+  const int PH = seg_th + 2;
   const int plane = PH * PWP;
   const int samp = KC * plane;
 
@@ -126,32 +155,61 @@ __global__ __launch_bounds__(256) void modconv_mfma_f32(const MCParams p) {
 #pragma unroll
   for (int g = 0; g < RNP; ++g) {
     const int pos = (wn * RNP + g) * 32 + l31;
-    const int tx = pos % TW, r = pos / TW;
-    const int ty = r % p.th, nbi = r / p.th;
+    const int tx = pos & (TW - 1), r = pos >> tw_log2;
+    const int ty = r % seg_th, nbi = r / seg_th;
     pbase[g] = nbi * samp + ty * PWP + tx;
     pos_b[g] = b0 + nbi; pos_y[g] = y0 + ty; pos_x[g] = x0 + tx;
   }
 
-  f32x16 acc[RM][RN];
+  f32x16 acc[RM][RNP][NPH];
 #pragma unroll
   for (int a = 0; a < RM; ++a)
 #pragma unroll
-    for (int b = 0; b < RN; ++b)
+    for (int b = 0; b < RNP; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int c = 0; c < NPH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
-  const int xs_total = p.nb * samp;
   const bool wvec = (p.cout & 3) == 0;
+  const int i_begin = ks * p.cin_per_split;
+  const int i_end = min(p.cin, i_begin + p.cin_per_split);
+  const int hw = p.h * p.w;
 
-  for (int i0 = 0; i0 < p.cin; i0 += KC) {
-    __syncthreads();
-    // ---- stage weights  Ws[(kc*9+t)*BM + o]
-    for (int idx = tid; idx < KC * 9 * (BM / 4); idx += 256) {
+  // ---- staging plan, fixed for the whole K loop.
+  // Patch: thread owns up to NU spatial slots (sample, row, col) of the halo patch and moves all KC channels of
+  // each; weights: NWV float4 per thread.  Everything a chunk needs is loaded into registers one chunk AHEAD
+  // (while the previous chunk is on the matrix pipe) and written to LDS after the barrier.
+  constexpr int BNP = 32 * RNP * WN;
+  constexpr int NU = ((BNP / 32 + 2) * 34 + 255) / 256;          // covers a full-width main tile
+  constexpr int NWV = (KC * 9 * (BM / 4) + 255) / 256;
+  const int spatial = seg_nb * plane;                              // patch slots per channel
+  // element offsets are 32-bit, relative to the tile's first sample (host checks nb*cin*h*w < 2^31)
+  const float* in_b0 = p.in + (long long)b0 * p.cin * hw;
+  const float* style_b0 = p.style + (long long)b0 * p.cin;
+  int gofs[NU], lofs[NU], sofs[NU]; bool inb[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int q = tid + 256 * u;
+    const int c = q % PWP;
+    int t = q / PWP;
+    const int r = t % PH, nbi = t / PH;
+    const int b = b0 + nbi, y = y0 + r - 1, x = x0 + c - 1;
+    inb[u] = q < spatial && b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
+    gofs[u] = (nbi * p.cin * p.h + y) * p.w + x;
+    sofs[u] = nbi * p.cin;
+    lofs[u] = q < spatial ? nbi * samp + r * PWP + c : -1;
+  }
+  float xv[NU][KC];
+  f32x4 wv[NWV];
+  auto issue = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) {
+      const int idx = tid + 256 * j;
       const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-      const int i = i0 + row / 9;
-      const int o = o0 + c4 * 4;
+      const int i = i0 + row / 9, o = o0 + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < p.cin) {
+      if (idx < KC * 9 * (BM / 4) && i < i_end) {
         const float* src = p.wt + ((long long)i * 9 + row % 9) * p.cout + o;
         if (wvec && o + 3 < p.cout) {
           v = *reinterpret_cast<const f32x4*>(src);
@@ -162,71 +220,125 @@ __global__ __launch_bounds__(256) void modconv_mfma_f32(const MCParams p) {
           if (o + 3 < p.cout) v.w = src[3];
         }
       }
-      *reinterpret_cast<f32x4*>(Ws + row * BM + c4 * 4) = v;
+      wv[j] = v;
     }
-    // ---- stage modulated input patch  Xs[nb][kc][r][c], origin (y0-1, x0-1)
-    for (int idx = tid; idx < xs_total; idx += 256) {
-      const int c = idx % PWP;
-      int t = idx / PWP;
-      const int r = t % PH; t /= PH;
-      const int kc = t % KC, nbi = t / KC;
-      const int b = b0 + nbi, i = i0 + kc, y = y0 + r - 1, x = x0 + c - 1;
-      float v = 0.f;
-      if (b < p.batch && i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w) {
-        const long long ch = (long long)b * p.cin + i;
-        v = p.in[(ch * p.h + y) * p.w + x] * p.style[ch];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int i = i0 + kc;
+        xv[u][kc] = (inb[u] && i < i_end) ? in_b0[gofs[u] + i * hw] : 0.f;
       }
-      Xs[idx] = v;
+  };
+  auto commit = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < NWV; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < KC * 9 * (BM / 4)) *reinterpret_cast<f32x4*>(Ws + idx * 4) = wv[j];
     }
+    // modulate on the way in: x[b,i] * style[b,i] (the style loads are L1 hits, issued ahead of the weight writes)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (lofs[u] >= 0) {
+        float sv[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) sv[kc] = (inb[u] && i0 + kc < i_end) ? style_b0[sofs[u] + i0 + kc] : 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Xs[lofs[u] + kc * plane] = xv[u][kc] * sv[kc];
+      }
+    // patches larger than a main tile's (sample-packed tiny layers, thin edge segments): synchronous remainder
+    for (int q = tid + 256 * NU; q < spatial; q += 256) {
+      const int c = q % PWP;
+      int t = q / PWP;
+      const int r = t % PH, nbi = t / PH;
+      const int b = b0 + nbi, y = y0 + r - 1, x = x0 + c - 1;
+      const bool ok = b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
+      for (int kc = 0; kc < KC; ++kc) {
+        const int i = i0 + kc;
+        float v = 0.f;
+        if (ok && i < i_end) {
+          const long long ch = (long long)b * p.cin + i;
+          v = p.in[(ch * p.h + y) * p.w + x] * p.style[ch];
+        }
+        Xs[nbi * samp + kc * plane + r * PWP + c] = v;
+      }
+    }
+  };
+
+  // LDS -> registers, one pipeline stage = one row of taps (MODE 0: 3 taps x channel pair) or one channel pair
+  // (MODE 1: its 9 taps share 4 input offsets).  Stage s+1 is fetched while stage s is on the matrix pipe.
+  constexpr int NTA = MODE == 1 ? 9 : 3;     // A (weight) values per stage per 32-row tile
+  constexpr int NTB = MODE == 1 ? 4 : 3;     // B (input) values per stage per position group
+  constexpr int NSTAGE = (KC / 2) * (MODE == 1 ? 1 : 3);
+  struct Ops { float a[NTA][RM]; float b[NTB][RNP]; };
+  auto fetch = [&](Ops& o, int st) {
+    const int kk = MODE == 1 ? st : st / 3, ky = MODE == 1 ? 0 : st % 3;
+    const int kc = 2 * kk + khalf;
+    const float* wrow = Ws + (kc * 9 + ky * 3) * BM + wm * 32 * RM + l31;
+    const float* xrow = Xs + kc * plane;
+#pragma unroll
+    for (int t = 0; t < NTA; ++t)
+#pragma unroll
+      for (int m = 0; m < RM; ++m) o.a[t][m] = wrow[t * BM + m * 32];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+      // MODE 0: offset (ky, kx = j); MODE 1: j -> (ro, co) = (1,1) (1,0) (0,1) (0,0)
+      const int ro = MODE == 1 ? 1 - (j >> 1) : ky;
+      const int co = MODE == 1 ? 1 - (j & 1) : j;
+#pragma unroll
+      for (int g = 0; g < RNP; ++g) o.b[j][g] = xrow[pbase[g] + ro * PWP + co];
+    }
+  };
+  auto mma = [&](const Ops& o) {
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < RM; ++m)
+#pragma unroll
+          for (int g = 0; g < RNP; ++g)
+            acc[m][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[t][m], o.b[t][g], acc[m][g][0], 0, 0, 0);
+    } else {
+      // (tap = ky*3+kx, input-offset index j, phase = py*2+px)
+      constexpr int T[9][3] = {{0, 0, 0}, {2, 1, 0}, {6, 2, 0}, {8, 3, 0}, {1, 0, 1}, {7, 2, 1}, {3, 0, 2}, {5, 1, 2}, {4, 0, 3}};
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int m = 0; m < RM; ++m)
+#pragma unroll
+          for (int g = 0; g < RNP; ++g)
+            acc[m][g][T[q][2]] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[T[q][0]][m], o.b[T[q][1]][g], acc[m][g][T[q][2]], 0, 0, 0);
+    }
+  };
+
+  if (i_begin < i_end) issue(i_begin);
+  for (int i0 = i_begin; i0 < i_end; i0 += KC) {
+    __syncthreads();            // every wave is done reading the previous chunk
+    commit(i0);
     __syncthreads();
-    // ---- contract
-#pragma unroll 2
-    for (int kk = 0; kk < KC / 2; ++kk) {
-      const int kc = 2 * kk + khalf;
-      const float* wrow = Ws + kc * 9 * BM + wm * 32 * RM + l31;
-      const float* xrow = Xs + kc * plane;
-      if constexpr (MODE == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
+    // ---- contract: operands of channel pair kk+1 are fetched while pair kk is on the matrix pipe.
+    // (hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) in front of each group of four:
+    // the sched_barriers keep "issue all reads of pair kk+1, then run pair kk's MFMAs" as written.)
+    Ops cur, nxt;
+    fetch(cur, 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          float a[RM], bv[RN];
-#pragma unroll
-          for (int m = 0; m < RM; ++m) a[m] = wrow[t * BM + m * 32];
-#pragma unroll
-          for (int g = 0; g < RN; ++g) bv[g] = xrow[pbase[g] + (t / 3) * PWP + (t % 3)];
-#pragma unroll
-          for (int m = 0; m < RM; ++m)
-#pragma unroll
-            for (int g = 0; g < RN; ++g)
-              acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[g], acc[m][g], 0, 0, 0);
-        }
-      } else {
-        // out[Y=2m+py, X=2n+px] += w[ky][kx] * in[m - ky/2, n - kx/2],  ky = py (mod 2), kx = px (mod 2)
-        // patch offsets: ro = 1 - ky/2, co = 1 - kx/2
-        auto step = [&](int tap, int ro, int co, int px) {
-          float a[RM];
-#pragma unroll
-          for (int m = 0; m < RM; ++m) a[m] = wrow[tap * BM + m * 32];
-#pragma unroll
-          for (int g = 0; g < RNP; ++g) {
-            const float bvv = xrow[pbase[g] + ro * PWP + co];
-#pragma unroll
-            for (int m = 0; m < RM; ++m)
-              acc[m][g * 2 + px] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bvv, acc[m][g * 2 + px], 0, 0, 0);
-          }
-        };
-        if (py == 0) {
-          step(0, 1, 1, 0); step(2, 1, 0, 0); step(6, 0, 1, 0); step(8, 0, 0, 0);  // (ky,kx) = 00 02 20 22
-          step(1, 1, 1, 1); step(7, 0, 1, 1);                                      // 01 21
-        } else {
-          step(3, 1, 1, 0); step(5, 1, 0, 0);                                      // 10 12
-          step(4, 1, 1, 1);                                                        // 11
-        }
-      }
+    for (int st = 0; st < NSTAGE; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < NSTAGE) fetch(nxt, st + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < NSTAGE) cur = nxt;
     }
   }
 
   // ---- epilogue
   const float nw = (p.fuse_act && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
+  const bool partial = p.ksplit > 1;
+  float* dstbase = partial ? p.ws + (long long)ks * p.batch * p.cout * p.oh * p.ow : p.out;
 #pragma unroll
   for (int m = 0; m < RM; ++m) {
 #pragma unroll
@@ -237,28 +349,30 @@ __global__ __launch_bounds__(256) void modconv_mfma_f32(const MCParams p) {
       for (int g = 0; g < RNP; ++g) {
         const int b = pos_b[g];
         if (b >= p.batch) continue;
-        const float d = p.demod ? p.demod[(long long)b * p.cout + o] : 1.f;
+        float* dplane = dstbase + ((long long)b * p.cout + o) * p.oh * p.ow;
         if constexpr (MODE == 0) {
           const int y = pos_y[g], x = pos_x[g];
           if (y >= p.h || x >= p.w) continue;
-          float v = acc[m][g][r] * d;
-          if (p.fuse_act) {
-            const float n = p.noise ? p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * p.h * p.w + y * p.w + x] : 0.f;
-            const float bv = p.bias ? p.bias[o] : 0.f;
-            v = __fadd_rn(__fadd_rn(v, __fmul_rn(nw, n)), bv);
-            v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
-          }
-          p.out[(((long long)b * p.cout + o) * p.h + y) * p.w + x] = v;
+          const int pix = y * p.w + x;
+          float v = acc[m][g][0][r];
+          if (!partial) v = mc_epilogue(v, p, nw, b, o, pix);
+          dplane[pix] = v;
         } else {
-          const int Y = 2 * pos_y[g] + py, X = 2 * pos_x[g];
-          if (Y >= p.oh || X >= p.ow) continue;
-          float* dst = p.out + (((long long)b * p.cout + o) * p.oh + Y) * p.ow + X;
-          const float v0 = acc[m][g * 2][r] * d, v1 = acc[m][g * 2 + 1][r] * d;
-          if (X + 1 < p.ow) {
-            f32x2_u t; t.x = v0; t.y = v1;
-            *reinterpret_cast<f32x2_u*>(dst) = t;
-          } else {
-            dst[0] = v0;
+          if (pos_y[g] >= seg_m_end || pos_x[g] >= seg_n_end) continue;
+          const int X = 2 * pos_x[g];
+          const float d = (!partial && p.demod) ? p.demod[(long long)b * p.cout + o] : 1.f;
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const int Y = 2 * pos_y[g] + py;
+            if (Y >= p.oh || X >= p.ow) continue;
+            float* dst = dplane + (long long)Y * p.ow + X;
+            const float v0 = acc[m][g][py * 2][r] * d, v1 = acc[m][g][py * 2 + 1][r] * d;
+            if (X + 1 < p.ow) {
+              f32x2_u t; t.x = v0; t.y = v1;
+              *reinterpret_cast<f32x2_u*>(dst) = t;
+            } else {
+              dst[0] = v0;
+            }
           }
         }
       }
@@ -266,44 +380,104 @@ __global__ __launch_bounds__(256) void modconv_mfma_f32(const MCParams p) {
   }
 }
 
-template <int MODE, int RM, int RN, int WM, int WN, int TW>
-int launch_cfg(MCParams& p, int gh, int gw, hipStream_t s) {
-  constexpr int BM = 32 * RM * WM;
-  constexpr int NPX = MODE == 1 ? 2 : 1;
-  constexpr int BN = 32 * (RN / NPX) * WN;
+// split-K finish: out = epilogue(sum_ks ws[ks])
+__global__ __launch_bounds__(256) void modconv_splitk_finish_f32(const MCParams p) {
+  const float nw = (p.fuse_act && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
+  const int hw = p.oh * p.ow;
+  const long long total = (long long)p.batch * p.cout * hw;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int ks = 0; ks < p.ksplit; ++ks) v += p.ws[ks * total + idx];
+    const int pix = (int)(idx % hw);
+    const long long bo = idx / hw;
+    p.out[idx] = mc_epilogue(v, p, nw, (int)(bo / p.cout), (int)(bo % p.cout), pix);
+  }
+}
+
+inline int pick_tw_log2(int gw) { return gw <= 4 ? 2 : (gw <= 8 ? 3 : (gw <= 16 ? 4 : 5)); }
+
+// tile plan of one segment; returns its block count (without the o_tiles factor) and LDS floats for the patch
+inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
+  sg.tw_log2 = pick_tw_log2(sg.gw);
+  const int TW = 1 << sg.tw_log2;
   const int rows_total = BN / TW;
   int th = rows_total, nb = 1;
-  if (gh < rows_total) {
+  if (sg.gh < rows_total) {
     th = 1;
-    while (th < gh) th <<= 1;
+    while (th < sg.gh) th <<= 1;
     nb = rows_total / th;
   }
-  p.th = th; p.nb = nb;
-  p.tiles_x = (gw + TW - 1) / TW;
-  p.tiles_y = (gh + th - 1) / th;
-  p.tiles_b = (p.batch + nb - 1) / nb;
+  sg.th = th; sg.nb = nb;
+  sg.tiles_x = (sg.gw + TW - 1) / TW;
+  sg.tiles_y = (sg.gh + th - 1) / th;
+  sg.tiles_b = (batch + nb - 1) / nb;
+  return (long long)sg.tiles_x * sg.tiles_y * sg.tiles_b;
+}
+
+template <int MODE, int RM, int RNP, int WM, int WN>
+int launch_cfg(MCParams& p, hipStream_t s) {
+  constexpr int BM = 32 * RM * WM, BN = 32 * RNP * WN;
   p.o_tiles = (p.cout + BM - 1) / BM;
-  const long long blocks = (long long)p.o_tiles * p.tiles_x * p.tiles_y * p.tiles_b;
-  if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
-  const size_t lds = sizeof(float) * ((size_t)MC_KC * 9 * BM + (size_t)nb * MC_KC * (th + 2) * (TW + 2));
-  hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RN, WM, WN, TW>), dim3((unsigned)blocks, MODE == 1 ? 2 : 1), dim3(256),
-                     lds, s, p);
+  long long blocks = 0;
+  size_t patch = 0;
+  for (int i = 0; i < p.nseg; ++i) {
+    blocks += plan_segment(p.seg[i], p.batch, BN) * p.o_tiles;
+    if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+    p.seg[i].block_end = (unsigned)blocks;
+    // 32-bit in-tile element offsets: (nb samples) x cin x h x w must fit
+    if ((long long)p.seg[i].nb * p.cin * p.h * p.w >= (1LL << 31)) return FMGAN_EOVERFLOW;
+    const size_t f = (size_t)p.seg[i].nb * MC_KC * (p.seg[i].th + 2) * ((1 << p.seg[i].tw_log2) + 2);
+    if (f > patch) patch = f;
+  }
+  const size_t lds = sizeof(float) * ((size_t)MC_KC * 9 * BM + patch);
+  hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RNP, WM, WN>), dim3((unsigned)blocks, p.ksplit), dim3(256), lds, s, p);
   return fmgan_check_launch();
 }
 
-template <int MODE, int RM, int RN, int WM, int WN>
-int launch_tw(MCParams& p, int gh, int gw, hipStream_t s) {
-  if (gw <= 4) return launch_cfg<MODE, RM, RN, WM, WN, 4>(p, gh, gw, s);
-  if (gw <= 8) return launch_cfg<MODE, RM, RN, WM, WN, 8>(p, gh, gw, s);
-  if (gw <= 16) return launch_cfg<MODE, RM, RN, WM, WN, 16>(p, gh, gw, s);
-  return launch_cfg<MODE, RM, RN, WM, WN, 32>(p, gh, gw, s);
+// tile configuration: 0 = 128(o) x 128(pos), 1 = 64 x 256 (mode 1: 64 x 128), 2 = 32 x 512 (mode 1: 32 x 256), 3 = 32 x 128
+inline int pick_cfg(int mode, int cout, long long positions) {
+  if (mode == 0) {
+    if (positions <= 2048) return 3;          // tiny layers: many small tiles (+ split-K)
+    return cout >= 96 ? 0 : (cout >= 48 ? 1 : 2);
+  }
+  return cout >= 48 ? 1 : 2;
 }
 
-template <int MODE>
-int launch_mode(MCParams& p, int gh, int gw, hipStream_t s) {
-  if (p.cout >= 96) return launch_tw<MODE, 2, 2, 2, 2>(p, gh, gw, s);  // 128 x 128 (mode 1: 64 pos x 2 px)
-  if (p.cout >= 48) return launch_tw<MODE, 2, 2, 1, 4>(p, gh, gw, s);  //  64 x 256
-  return launch_tw<MODE, 1, 4, 1, 4>(p, gh, gw, s);                    //  32 x 512
+inline void cfg_dims(int mode, int cfg, int& BM, int& BN) {
+  if (mode == 0) {
+    const int bm[4] = {128, 64, 32, 32}, bn[4] = {128, 256, 512, 128};
+    BM = bm[cfg]; BN = bn[cfg];
+  } else {
+    BM = cfg == 1 ? 64 : 32; BN = cfg == 1 ? 128 : 256;
+  }
+}
+
+inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
+  if (mode == 0) {
+    switch (cfg) {
+      case 0: return launch_cfg<0, 2, 2, 2, 2>(p, s);
+      case 1: return launch_cfg<0, 2, 2, 1, 4>(p, s);
+      case 2: return launch_cfg<0, 1, 4, 1, 4>(p, s);
+      default: return launch_cfg<0, 1, 1, 1, 4>(p, s);
+    }
+  }
+  return cfg == 1 ? launch_cfg<1, 2, 1, 1, 4>(p, s) : launch_cfg<1, 1, 2, 1, 4>(p, s);
+}
+
+// split-K factor so that a tiny layer still fills the chip; 1 when the layer already has enough blocks
+inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
+  const long long positions = (long long)batch * h * w;
+  const int cfg = pick_cfg(mode, cout, positions);
+  int BM, BN;
+  cfg_dims(mode, cfg, BM, BN);
+  const long long blocks = ((cout + BM - 1) / BM) * ((positions + BN - 1) / BN);
+  const int chunks = (cin + MC_KC - 1) / MC_KC;
+  if (blocks >= 384 || chunks < 8) return 1;
+  int ks = (int)((768 + blocks - 1) / blocks);
+  if (ks > 16) ks = 16;
+  if (ks > chunks / 2) ks = chunks / 2;
+  return ks < 2 ? 1 : ks;
 }
 
 // ------------------------------------------------------------------ ToRGB (1x1, <= 4 output channels, HBM-bound)
@@ -387,10 +561,19 @@ extern "C" int fmgan_modconv_weight_prep_f32(const float* weight, float* wt, int
   return fmgan_check_launch();
 }
 
+extern "C" long long fmgan_modconv2d_workspace_bytes(int batch, int cin, int cout, int h, int w, int mode) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (mode != 0 && mode != 1)) return 0;
+  const int ks = pick_ksplit(mode, batch, cin, cout, h, w);
+  if (ks <= 1) return 0;
+  const long long oh = mode == 1 ? 2 * h + 1 : h, ow = mode == 1 ? 2 * w + 1 : w;
+  return (long long)ks * batch * cout * oh * ow * (long long)sizeof(float);
+}
+
 extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float* style, const float* demod,
                                    float* out, int batch, int cin, int cout, int h, int w, int mode,
                                    const float* noise, const float* noise_weight, const float* bias, int noise_batch,
-                                   int fuse_act, float alpha, float act_scale, void* stream) {
+                                   int fuse_act, float alpha, float act_scale, void* workspace,
+                                   long long workspace_bytes, void* stream) {
   if (batch < 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return FMGAN_EINVAL;
   if (mode != 0 && mode != 1) return FMGAN_EUNSUPPORTED;
   if (mode == 1 && fuse_act) return FMGAN_EUNSUPPORTED;  // the blur sits between conv and activation
@@ -406,8 +589,34 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
   p.noise_batch = noise_batch; p.fuse_act = fuse_act; p.alpha = alpha; p.act_scale = act_scale;
   if ((long long)batch * cout * p.oh * p.ow > (1LL << 40)) return FMGAN_EOVERFLOW;
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) return launch_mode<0>(p, h, w, s);
-  return launch_mode<1>(p, h + 1, w + 1, s);  // position grid (m, n): Y = 2m+py, X = 2n+px
+  const int cfg = pick_cfg(mode, cout, (long long)batch * h * w);
+  // split-K only when the caller supplied the workspace fmgan_modconv2d_workspace_bytes() asks for
+  p.ksplit = pick_ksplit(mode, batch, cin, cout, h, w);
+  const long long need = (long long)p.ksplit * batch * cout * p.oh * p.ow * (long long)sizeof(float);
+  if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) p.ksplit = 1;
+  p.ws = (float*)workspace;
+  const int chunks = (cin + MC_KC - 1) / MC_KC;
+  p.cin_per_split = ((chunks + p.ksplit - 1) / p.ksplit) * MC_KC;
+  // segment 0: the h x w grid.  Mode 1: quads (2m+py, 2n+px) of m < h, n < w cover Y < 2h, X < 2w; the last
+  // output row (m = h) and column (n = w) are two thin segments of the same launch, so they run beside the
+  // main tiles instead of serialising their own latency-bound K loops.
+  p.seg[0] = {0, 0, h, w};
+  p.nseg = 1;
+  if (mode == 1) {
+    p.seg[1] = {h, 0, 1, w + 1};
+    p.seg[2] = {0, w, h, 1};
+    p.nseg = 3;
+  }
+  int st = launch_any(mode, cfg, p, s);
+  if (st != FMGAN_OK) return st;
+  if (p.ksplit > 1) {
+    const long long total = (long long)batch * cout * p.oh * p.ow;
+    long long blocks = (total + 255) / 256;
+    if (blocks > FMGAN_NUM_CU * 16) blocks = FMGAN_NUM_CU * 16;
+    hipLaunchKernelGGL(modconv_splitk_finish_f32, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    st = fmgan_check_launch();
+  }
+  return st;
 }
 
 extern "C" int fmgan_torgb_f32(const float* in, const float* weight, const float* style, const float* bias,

@@ -96,32 +96,37 @@ __device__ __forceinline__ void load_seg(float (&dst)[VEC], const float* __restr
   }
 }
 
-// Row `iy` of the plane, columns a0 .. a0+VEC+2 for this lane.  Lane l loads segment l
-// (VEC floats); the 3 halo columns are elements of segments l+1.. held by the next lanes; the
-// segments past lane 63 are loaded by lanes 0..NX-1 as an extra segment and rotated in.
+// Row `iy` of the plane, columns a0 .. a0+VEC+2 for this lane, in two halves so the HBM latency can be
+// covered: issue_row() only issues the global loads (lane l loads segment l = VEC floats; the segments past
+// lane 63 are loaded by lanes 0..NX-1 as an extra segment); finish_row() — called two rows later — rotates the
+// 3 halo columns in from the next lanes by wave shuffle.
+template <int VEC> struct RawRow { float prim[VEC], extra[VEC]; };
+
 template <int VEC>
-__device__ __forceinline__ void load_row(Row<VEC>& r, const float* __restrict__ pin, int iy, bool need,
-                                         int in_h, int in_w, int a0, int lane) {
+__device__ __forceinline__ void issue_row(RawRow<VEC>& raw, const float* __restrict__ pin, int iy, bool need,
+                                          int in_h, int in_w, int a0, int lane) {
   constexpr int NX = (3 + VEC - 1) / VEC;
   const bool rowok = need && iy >= 0 && iy < in_h;  // wave-uniform
   const float* rp = pin + (long long)iy * in_w;
-  float prim[VEC], extra[VEC];
-  load_seg<VEC>(prim, rp, rowok, a0, in_w);
+  load_seg<VEC>(raw.prim, rp, rowok, a0, in_w);
   if (lane < NX) {
-    load_seg<VEC>(extra, rp, rowok, a0 + 64 * VEC, in_w);
+    load_seg<VEC>(raw.extra, rp, rowok, a0 + 64 * VEC, in_w);
   } else {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) extra[e] = 0.f;
+    for (int e = 0; e < VEC; ++e) raw.extra[e] = 0.f;
   }
+}
+
+template <int VEC>
+__device__ __forceinline__ void finish_row(Row<VEC>& r, const RawRow<VEC>& raw, int lane) {
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) r.v[e] = prim[e];
+  for (int e = 0; e < VEC; ++e) r.v[e] = raw.prim[e];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    constexpr int dummy = 0; (void)dummy;
     const int e = VEC + j;
     const int d = e / VEC;   // lane distance of the segment holding column a0+e
     const int el = e % VEC;  // element inside that segment
-    const float t = (lane < d) ? extra[el] : prim[el];
+    const float t = (lane < d) ? raw.extra[el] : raw.prim[el];
     r.v[e] = __shfl(t, (lane + d) & 63, 64);
   }
 }
@@ -191,22 +196,29 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
   float* pout = out + plane * (long long)p.out_h * p.out_w;
   const int iy0 = oy0 - p.pad_y0;
 
+  // Rolling 4-row register window (statically unrolled by 4) fed by a 2-deep ring of in-flight row loads:
+  // while row r is filtered, rows r+1 and r+2 are on their way from HBM.
   Row<VEC> w0, w1, w2, w3;
-  load_row<VEC>(w0, pin, iy0 + 0, true, p.in_h, p.in_w, a0, lane);
-  load_row<VEC>(w1, pin, iy0 + 1, true, p.in_h, p.in_w, a0, lane);
-  load_row<VEC>(w2, pin, iy0 + 2, true, p.in_h, p.in_w, a0, lane);
+  RawRow<VEC> ra, rb;
+#define ISSUE(raw, k, need) issue_row<VEC>(raw, pin, iy0 + (k), need, p.in_h, p.in_w, a0, lane)
+  ISSUE(ra, 0, true); ISSUE(rb, 1, true);
+  finish_row<VEC>(w0, ra, lane); ISSUE(ra, 2, true);
+  finish_row<VEC>(w1, rb, lane); ISSUE(rb, 3, true);
+  finish_row<VEC>(w2, ra, lane); ISSUE(ra, 4, oy0 + 1 < oy_end);
+  // invariant at loop top (r): w0..w2 = rows r..r+2; rb = row r+3 in flight, ra = row r+4 in flight
   for (int r = 0; r < p.th; r += 4) {
     const int oy = oy0 + r;
     if (oy >= oy_end) break;  // wave-uniform
-    load_row<VEC>(w3, pin, iy0 + r + 3, true, p.in_h, p.in_w, a0, lane);
+    finish_row<VEC>(w3, rb, lane); ISSUE(rb, r + 5, oy + 2 < oy_end);
     emit_row<VEC>(pout, oy + 0, oy_end, p.out_w, c0, kf, w0, w1, w2, w3);
-    load_row<VEC>(w0, pin, iy0 + r + 4, oy + 1 < oy_end, p.in_h, p.in_w, a0, lane);
+    finish_row<VEC>(w0, ra, lane); ISSUE(ra, r + 6, oy + 3 < oy_end);
     emit_row<VEC>(pout, oy + 1, oy_end, p.out_w, c0, kf, w1, w2, w3, w0);
-    load_row<VEC>(w1, pin, iy0 + r + 5, oy + 2 < oy_end, p.in_h, p.in_w, a0, lane);
+    finish_row<VEC>(w1, rb, lane); ISSUE(rb, r + 7, oy + 4 < oy_end && r + 4 < p.th);
     emit_row<VEC>(pout, oy + 2, oy_end, p.out_w, c0, kf, w2, w3, w0, w1);
-    load_row<VEC>(w2, pin, iy0 + r + 6, oy + 3 < oy_end, p.in_h, p.in_w, a0, lane);
+    finish_row<VEC>(w2, ra, lane); ISSUE(ra, r + 8, oy + 5 < oy_end && r + 4 < p.th);
     emit_row<VEC>(pout, oy + 3, oy_end, p.out_w, c0, kf, w3, w0, w1, w2);
   }
+#undef ISSUE
 }
 
 template <typename T>

@@ -44,7 +44,8 @@ def lib():
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, vp])
-    _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, vp])
+    _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
+    _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, vp, ll, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
     if L.fmgan_abi_version() != 1:
         raise RuntimeError('libfmgan_hip.so ABI version mismatch')
@@ -214,11 +215,14 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
     oh, ow = (2 * h + 1, 2 * w + 1) if mode == 1 else (h, w)
     out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=x.device)
     nz = noise.contiguous() if noise is not None else None
+    ws_bytes = lib().fmgan_modconv2d_workspace_bytes(b, cin, cout, h, w, mode)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with on_device(x) as stream:
         tok = _observer.begin('modconv2d', (b, cin, cout, h, w, mode))
         check(lib().fmgan_modconv2d_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), ptr(out), b, cin, cout, h, w, mode,
                                         ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
-                                        int(bool(fuse_act)), float(alpha), float(act_scale), stream), 'modconv2d')
+                                        int(bool(fuse_act)), float(alpha), float(act_scale), ptr(ws), ws_bytes,
+                                        stream), 'modconv2d')
         _observer.end(tok)
     return out
 

@@ -117,15 +117,30 @@ def timed(step, steps, warmup, world):
     return dt
 
 
+def host_cores():
+    """Cores this process may actually use: cgroup quota if set, else the affinity mask, capped at the 16-core
+    share a one-GPU box gets (FMGAN_CPU_CORES overrides)."""
+    if os.environ.get('FMGAN_CPU_CORES'):
+        return int(os.environ['FMGAN_CPU_CORES'])
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline(nets, inputs, size, budget_s=20.0):
     """The reference's pure-PyTorch CPU path as restated in oracle/torch_oracle.py (pinned to the reference by
     tests/test_oracle_golden.py), on this box's host cores, B=1 pairs of the same workload until ~budget_s."""
     from oracle import torch_oracle as T
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     sds = {k: {n: v.detach().cpu() for n, v in m.state_dict().items()} for k, m in nets.items()}
     photo, render = (t[:1].cpu() for t in inputs)

@@ -139,13 +139,19 @@ int fmgan_modconv_weight_prep_f32(const float *weight, float *wt, int cout, int 
  *   out = lrelu( (conv + noise_weight[0]*noise[b or 0,y,x]) + bias[o] ) * act_scale
  *   noise [noise_batch (1 or batch), h*w] or NULL, noise_weight device scalar or NULL, bias [cout] or NULL.
  * The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).
+ * workspace: tiny layers (4x4..32x32 at small batch) have too few output tiles to fill 256 CUs, so the
+ *   input-channel loop is split over blocks (split-K) and the partial sums are combined by a finish kernel.
+ *   Pass a device buffer of at least fmgan_modconv2d_workspace_bytes() bytes (0 = no split for this shape);
+ *   with workspace == NULL the call still works, unsplit.  Results do not depend on timing or placement
+ *   (no atomics: each partial slab is written once and summed in a fixed order).
  */
+long long fmgan_modconv2d_workspace_bytes(int batch, int cin, int cout, int h, int w, int mode);
 int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
                         const float *demod, float *out,
                         int batch, int cin, int cout, int h, int w, int mode,
                         const float *noise, const float *noise_weight, const float *bias,
                         int noise_batch, int fuse_act, float alpha, float act_scale,
-                        void *stream);
+                        void *workspace, long long workspace_bytes, void *stream);
 
 /*
  * ToRGB (stylegan2.py:389-404): 1x1 modulated conv without demodulation + bias + optional skip:
