@@ -221,6 +221,120 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
 #undef ISSUE
 }
 
+// ---------------------------------------------------------------- path 2: plane-tile (f32, up=down=1, k<=4x4, small planes)
+// Planes of 4..65 px are too narrow for a wave-wide strip.  A block stages PB whole planes (contiguous in memory,
+// so the copy is one flat coalesced stream) in LDS and each thread filters consecutive outputs from there.
+struct PTParams {
+  int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw, pb;
+};
+
+__global__ __launch_bounds__(256) void ufd_planetile_f32(const float* __restrict__ in, const float* __restrict__ kern,
+                                                         float* __restrict__ out, const PTParams p) {
+  extern __shared__ float tile[];
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+      kf[ky][kx] = (ky < p.kh && kx < p.kw) ? kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
+  const int plane0 = blockIdx.x * p.pb;
+  const int np = min(p.pb, p.planes - plane0);
+  const int in_sz = p.in_h * p.in_w, out_sz = p.out_h * p.out_w;
+  const float* src = in + (long long)plane0 * in_sz;
+  for (int i = threadIdx.x; i < np * in_sz; i += 256) tile[i] = src[i];
+  __syncthreads();
+  float* dst = out + (long long)plane0 * out_sz;
+  for (int o = threadIdx.x; o < np * out_sz; o += 256) {
+    const int pl = o / out_sz, r = o - pl * out_sz;
+    const int oy = r / p.out_w, ox = r - oy * p.out_w;
+    const float* tp = tile + pl * in_sz;
+    float v = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = oy + ky - p.pad_y0;
+      const bool yok = iy >= 0 && iy < p.in_h;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int ix = ox + kx - p.pad_x0;
+        const float x = (yok && ix >= 0 && ix < p.in_w) ? tp[iy * p.in_w + ix] : 0.f;
+        v = fmaf(x, kf[ky][kx], v);
+      }
+    }
+    dst[o] = v;
+  }
+}
+
+// ---------------------------------------------------------------- path 3: up=2 polyphase (f32, down=1, k<=4x4)
+// ToRGB skip upsample: out is 4x the input, so the kernel is store-bound.  A thread owns a 2-row x 4-column output
+// block (two dwordx4 stores); for each output only the taps whose zero-stuffed sample is non-zero are visited
+// (ky = (pad_y0 - oy) mod 2, +2: 2x2 of the 4x4 taps), inputs come through L1 (each is reused by ~4 threads).
+struct U2Params {
+  int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw, bw, bh;   // bw/bh: 4x2 blocks per row/col
+};
+
+__global__ __launch_bounds__(256) void ufd_up2_f32(const float* __restrict__ in, const float* __restrict__ kern,
+                                                   float* __restrict__ out, const U2Params p) {
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+      kf[ky][kx] = (ky < p.kh && kx < p.kw) ? kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
+  const long long total = (long long)p.planes * p.bh * p.bw;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int bx = (int)(idx % p.bw);
+    const long long t = idx / p.bw;
+    const int by = (int)(t % p.bh);
+    const long long pl = t / p.bh;
+    const float* pin = in + pl * (long long)p.in_h * p.in_w;
+    float* pout = out + pl * (long long)p.out_h * p.out_w;
+    const int ox0 = bx * 4, oy0 = by * 2;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int oy = oy0 + dy;
+      if (oy >= p.out_h) break;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const int ky0 = (p.pad_y0 - oy) & 1;          // taps with (oy + ky - pad_y0) even
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ky = ky0 + 2 * a;
+        const int uy = oy + ky - p.pad_y0;           // even by construction; arithmetic shift = floor for negatives
+        const int iy = uy >> 1;
+        const bool yok = uy >= 0 && iy < p.in_h;
+        const float* rp = pin + (long long)iy * p.in_w;
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+          const int ox = ox0 + dx;
+          const int kx0 = (p.pad_x0 - ox) & 1;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int kx = kx0 + 2 * c;
+            const int ux = ox + kx - p.pad_x0;
+            const int ix = ux >> 1;
+            const float x = (yok && ux >= 0 && ix < p.in_w) ? rp[ix] : 0.f;
+            // kf[ky][kx] with runtime (ky,kx) in {0..3}: select from registers
+            float w = 0.f;
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+              for (int xx = 0; xx < 4; ++xx) w = (yy == ky && xx == kx) ? kf[yy][xx] : w;
+            acc[dx] = fmaf(x, w, acc[dx]);
+          }
+        }
+      }
+      float* op = pout + (long long)oy * p.out_w + ox0;
+      if (ox0 + 4 <= p.out_w) {
+        f32x4_u t; t.x = acc[0]; t.y = acc[1]; t.z = acc[2]; t.w = acc[3];
+        *reinterpret_cast<f32x4_u*>(op) = t;
+      } else {
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+          if (ox0 + dx < p.out_w) op[dx] = acc[dx];
+      }
+    }
+  }
+}
+
 template <typename T>
 int launch_generic(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
   const long long total = (long long)p.major * p.out_h * p.out_w * p.minor;
@@ -263,6 +377,50 @@ int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams
   return fmgan_check_launch();
 }
 
+bool planetile_ok(int dtype, const UfdParams& p) {
+  return dtype == FMGAN_F32 && p.minor == 1 && p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1 &&
+         p.kh <= 4 && p.kw <= 4 && (long long)p.in_h * p.in_w <= 12288 && (long long)p.out_h * p.out_w <= (1 << 20);
+}
+
+int launch_planetile(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
+  PTParams t{p.major, p.in_h, p.in_w, p.out_h, p.out_w, p.pad_x0, p.pad_y0, p.kh, p.kw, 1};
+  const int in_sz = p.in_h * p.in_w;
+  int pb = 8192 / in_sz;                      // ~32 KB of LDS per block
+  if (pb < 1) pb = 1;
+  if (pb > 64) pb = 64;
+  // keep at least ~2 blocks per CU when the layer is small
+  while (pb > 1 && (p.major + pb - 1) / pb < 2 * FMGAN_NUM_CU) pb >>= 1;
+  t.pb = pb;
+  const unsigned blocks = (unsigned)((p.major + pb - 1) / pb);
+  hipLaunchKernelGGL(ufd_planetile_f32, dim3(blocks), dim3(256), sizeof(float) * (size_t)pb * in_sz, s,
+                     (const float*)in, (const float*)kern, (float*)out, t);
+  return fmgan_check_launch();
+}
+
+bool up2_ok(int dtype, const UfdParams& p) {
+  return dtype == FMGAN_F32 && p.minor == 1 && p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1 &&
+         p.kh <= 4 && p.kw <= 4;
+}
+
+int launch_up2(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
+  U2Params t{p.major, p.in_h, p.in_w, p.out_h, p.out_w, p.pad_x0, p.pad_y0, p.kh, p.kw, (p.out_w + 3) / 4,
+             (p.out_h + 1) / 2};
+  const long long total = (long long)p.major * t.bw * t.bh;
+  long long blocks = (total + 255) / 256;
+  const long long cap = (long long)FMGAN_NUM_CU * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(ufd_up2_f32, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in, (const float*)kern,
+                     (float*)out, t);
+  return fmgan_check_launch();
+}
+
+int pick_path(int dtype, const UfdParams& p) {
+  if (rowmarch_ok(dtype, p)) return 1;
+  if (planetile_ok(dtype, p)) return 2;
+  if (up2_ok(dtype, p)) return 3;
+  return 0;
+}
+
 int validate(int dtype, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x, int up_y, int down_x,
              int down_y) {
   if (dtype != FMGAN_F32 && dtype != FMGAN_F64 && dtype != FMGAN_F16) return FMGAN_EUNSUPPORTED;
@@ -292,8 +450,7 @@ extern "C" int fmgan_upfirdn2d_select(int dtype, int major, int in_h, int in_w, 
   fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
                            &p.out_h, &p.out_w);
   if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
-  if (rowmarch_ok(dtype, p)) return 1;
-  return 0;
+  return pick_path(dtype, p);
 }
 
 extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel, void* out, int major, int in_h,
@@ -312,7 +469,7 @@ extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel,
     return FMGAN_EOVERFLOW;
   hipStream_t s = (hipStream_t)stream;
   int path = force_path;
-  if (path < 0) path = rowmarch_ok(dtype, p) ? 1 : 0;
+  if (path < 0) path = pick_path(dtype, p);
   switch (path) {
     case 0:
       if (dtype == FMGAN_F32) return launch_generic<float>(input, kernel, out, p, s);
@@ -321,6 +478,12 @@ extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel,
     case 1:
       if (!rowmarch_ok(dtype, p)) return FMGAN_EUNSUPPORTED;
       return launch_rowmarch(input, kernel, out, p, s);
+    case 2:
+      if (!planetile_ok(dtype, p)) return FMGAN_EUNSUPPORTED;
+      return launch_planetile(input, kernel, out, p, s);
+    case 3:
+      if (!up2_ok(dtype, p)) return FMGAN_EUNSUPPORTED;
+      return launch_up2(input, kernel, out, p, s);
     default:
       return FMGAN_EUNSUPPORTED;
   }

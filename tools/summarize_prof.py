@@ -44,6 +44,28 @@ def main(out):
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             print(f'| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {k[4]} | {len(v)} | {sum(v) / len(v) / 1e3:.1f} | {sum(v) / 1e6:.3f} |')
         print()
+    # steady state: kernels between the last two launches of the headline blur = one full step
+    for f in find(os.path.join(out, 'trace'), '*kernel_trace.csv'):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+        marks = [i for i, r in enumerate(rows) if 'ufd_rowmarch_f32<4>' in r['Kernel_Name']]
+        big = max((int(rows[i]['Grid_Size_X']) for i in marks), default=0)
+        marks = [i for i in marks if int(rows[i]['Grid_Size_X']) == big]
+        if len(marks) >= 3:
+            step = rows[marks[-3]:marks[-2]]
+            t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
+            agg = defaultdict(lambda: [0, 0])
+            for r in step:
+                k = short(r['Kernel_Name'], 80)
+                agg[k][0] += 1
+                agg[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            tot = sum(v[1] for v in agg.values())
+            print(f'## one steady-state step (between two headline-blur launches): wall {(t1 - t0) / 1e6:.2f} ms, '
+                  f'{len(step)} kernels, sum of kernel time {tot / 1e6:.2f} ms\n')
+            print('| kernel | launches | total ms |')
+            print('|---|---|---|')
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+                print(f'| {k} | {v[0]} | {v[1] / 1e6:.3f} |')
+            print()
     for tag, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         for f in find(os.path.join(out, tag), '*counter_collection.csv'):
             agg = defaultdict(list)
