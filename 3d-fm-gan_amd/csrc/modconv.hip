@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void modconv_weight_prep_f32(const float* __re
 struct MCParams {
   const float* in; const float* wt; const float* style; const float* demod; float* out;
   int batch, cin, cout, h, w, oh, ow;
+  long long out_plane_stride; int out_row_stride;   // elements; contiguous: oh*ow and ow
   // Position grid = up to 3 rectangular segments tiled independently but launched together (mode 1: the h x w
   // quad grid plus the last output row and the last output column; mode 0: one segment h x w).
   struct Seg {
@@ -339,6 +340,8 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   const float nw = (p.fuse_act && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
   const bool partial = p.ksplit > 1;
   float* dstbase = partial ? p.ws + (long long)ks * p.batch * p.cout * p.oh * p.ow : p.out;
+  const long long dps = partial ? (long long)p.oh * p.ow : p.out_plane_stride;
+  const int drs = partial ? p.ow : p.out_row_stride;
 #pragma unroll
   for (int m = 0; m < RM; ++m) {
 #pragma unroll
@@ -349,14 +352,14 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
       for (int g = 0; g < RNP; ++g) {
         const int b = pos_b[g];
         if (b >= p.batch) continue;
-        float* dplane = dstbase + ((long long)b * p.cout + o) * p.oh * p.ow;
+        float* dplane = dstbase + ((long long)b * p.cout + o) * dps;
         if constexpr (MODE == 0) {
           const int y = pos_y[g], x = pos_x[g];
           if (y >= p.h || x >= p.w) continue;
           const int pix = y * p.w + x;
           float v = acc[m][g][0][r];
           if (!partial) v = mc_epilogue(v, p, nw, b, o, pix);
-          dplane[pix] = v;
+          dplane[(long long)y * drs + x] = v;
         } else {
           if (pos_y[g] >= seg_m_end || pos_x[g] >= seg_n_end) continue;
           const int X = 2 * pos_x[g];
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
           for (int py = 0; py < 2; ++py) {
             const int Y = 2 * pos_y[g] + py;
             if (Y >= p.oh || X >= p.ow) continue;
-            float* dst = dplane + (long long)Y * p.ow + X;
+            float* dst = dplane + (long long)Y * drs + X;
             const float v0 = acc[m][g][py * 2][r] * d, v1 = acc[m][g][py * 2 + 1][r] * d;
             if (X + 1 < p.ow) {
               f32x2_u t; t.x = v0; t.y = v1;
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(256) void modconv_splitk_finish_f32(const MCParams 
     for (int ks = 0; ks < p.ksplit; ++ks) v += p.ws[ks * total + idx];
     const int pix = (int)(idx % hw);
     const long long bo = idx / hw;
-    p.out[idx] = mc_epilogue(v, p, nw, (int)(bo / p.cout), (int)(bo % p.cout), pix);
+    p.out[bo * p.out_plane_stride + (long long)(pix / p.ow) * p.out_row_stride + pix % p.ow] =
+        mc_epilogue(v, p, nw, (int)(bo / p.cout), (int)(bo % p.cout), pix);
   }
 }
 
@@ -572,8 +576,8 @@ extern "C" long long fmgan_modconv2d_workspace_bytes(int batch, int cin, int cou
 extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float* style, const float* demod,
                                    float* out, int batch, int cin, int cout, int h, int w, int mode,
                                    const float* noise, const float* noise_weight, const float* bias, int noise_batch,
-                                   int fuse_act, float alpha, float act_scale, void* workspace,
-                                   long long workspace_bytes, void* stream) {
+                                   int fuse_act, float alpha, float act_scale, long long out_plane_stride,
+                                   int out_row_stride, void* workspace, long long workspace_bytes, void* stream) {
   if (batch < 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return FMGAN_EINVAL;
   if (mode != 0 && mode != 1) return FMGAN_EUNSUPPORTED;
   if (mode == 1 && fuse_act) return FMGAN_EUNSUPPORTED;  // the blur sits between conv and activation
@@ -585,6 +589,10 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
   p.oh = mode == 1 ? 2 * h + 1 : h;
   p.ow = mode == 1 ? 2 * w + 1 : w;
+  if (out_row_stride == 0) out_row_stride = p.ow;
+  if (out_plane_stride == 0) out_plane_stride = (long long)p.oh * out_row_stride;
+  if (out_row_stride < p.ow || out_plane_stride < (long long)p.oh * out_row_stride) return FMGAN_EINVAL;
+  p.out_plane_stride = out_plane_stride; p.out_row_stride = out_row_stride;
   p.noise = noise; p.noise_weight = noise_weight; p.bias = bias;
   p.noise_batch = noise_batch; p.fuse_act = fuse_act; p.alpha = alpha; p.act_scale = act_scale;
   if ((long long)batch * cout * p.oh * p.ow > (1LL << 40)) return FMGAN_EOVERFLOW;

@@ -27,6 +27,8 @@ struct UfdParams {
   int major, in_h, in_w, minor, kh, kw;
   int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
   int out_h, out_w;
+  long long in_plane_stride;   // elements between planes of the input (== in_h*in_w*minor when contiguous)
+  int in_row_stride;           // elements between rows of the input   (== in_w*minor when contiguous)
 };
 
 // ---------------------------------------------------------------- path 0: generic
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void ufd_generic(const T* __restrict__ in, con
     const long long mj = t / p.out_h;
     const int by = oy * p.down_y - p.pad_y0;
     const int bx = ox * p.down_x - p.pad_x0;
-    const T* pin = in + mj * (long long)p.in_h * p.in_w * p.minor + mi;
+    const T* pin = in + mj * p.in_plane_stride + mi;
     Acc v = 0;
     for (int ky = 0; ky < p.kh; ++ky) {
       const int uy = by + ky;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void ufd_generic(const T* __restrict__ in, con
         if (ux < 0 || (ux % p.up_x) != 0) continue;
         const int ix = ux / p.up_x;
         if (ix >= p.in_w) continue;
-        v += to_acc<T>(pin[((long long)iy * p.in_w + ix) * p.minor]) *
+        v += to_acc<T>(pin[(long long)iy * p.in_row_stride + (long long)ix * p.minor]) *
              to_acc<T>(kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)]);
       }
     }
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void ufd_generic(const T* __restrict__ in, con
 // ---------------------------------------------------------------- path 1: row-march (f32, up=down=1, k<=4x4, minor=1)
 struct RMParams {
   int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw;
+  long long in_plane_stride; int in_row_stride;
   int th;       // output rows per wave, multiple of 4
   int strips;   // 64*VEC-column strips per row
   int tiles_y;  // row tiles per plane
@@ -75,42 +78,49 @@ struct RMParams {
 
 template <int VEC> struct Row { float v[VEC + 3]; };
 
+// One segment of VEC floats at column `a` of row `rp`.  The load is a single (dword-aligned) vector load whenever
+// its bytes lie inside the tensor's memory [lo, hi) — columns outside [0, in_w) then hold a neighbouring row's data
+// and are zeroed later by the row-invariant masks of finish_row.  Only the first/last few floats of the whole
+// tensor need the per-element path, so edge lanes do not diverge in steady state.
 template <int VEC>
-__device__ __forceinline__ void load_seg(float (&dst)[VEC], const float* __restrict__ rp, bool rowok, int a, int in_w) {
-  if (!rowok) {
+__device__ __forceinline__ void load_seg(float (&dst)[VEC], const float* __restrict__ rp, bool rowok, int a, int in_w,
+                                         const float* lo, const float* hi) {
+  const float* q = rp + a;
+  if (!rowok || a >= in_w || a + VEC <= 0) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dst[e] = 0.f;
-  } else if (a >= 0 && a + VEC <= in_w) {
+  } else if (q >= lo && q + VEC <= hi) {
     if constexpr (VEC == 4) {
-      const f32x4_u t = *reinterpret_cast<const f32x4_u*>(rp + a);
+      const f32x4_u t = *reinterpret_cast<const f32x4_u*>(q);
       dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
     } else if constexpr (VEC == 2) {
-      const f32x2_u t = *reinterpret_cast<const f32x2_u*>(rp + a);
+      const f32x2_u t = *reinterpret_cast<const f32x2_u*>(q);
       dst[0] = t.x; dst[1] = t.y;
     } else {
-      dst[0] = rp[a];
+      dst[0] = q[0];
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) dst[e] = (a + e >= 0 && a + e < in_w) ? rp[a + e] : 0.f;
+    for (int e = 0; e < VEC; ++e) dst[e] = (a + e >= 0 && a + e < in_w) ? q[e] : 0.f;
   }
 }
 
 // Row `iy` of the plane, columns a0 .. a0+VEC+2 for this lane, in two halves so the HBM latency can be
 // covered: issue_row() only issues the global loads (lane l loads segment l = VEC floats; the segments past
-// lane 63 are loaded by lanes 0..NX-1 as an extra segment); finish_row() — called two rows later — rotates the
-// 3 halo columns in from the next lanes by wave shuffle.
+// lane 63 are loaded by lanes 0..NX-1 as an extra segment); finish_row() — called two rows later — zeroes the
+// out-of-range columns and rotates the 3 halo columns in from the next lanes by wave shuffle.
 template <int VEC> struct RawRow { float prim[VEC], extra[VEC]; };
 
 template <int VEC>
 __device__ __forceinline__ void issue_row(RawRow<VEC>& raw, const float* __restrict__ pin, int iy, bool need,
-                                          int in_h, int in_w, int a0, int lane) {
+                                          int in_h, int in_w, int in_rs, int a0, int lane, const float* lo,
+                                          const float* hi) {
   constexpr int NX = (3 + VEC - 1) / VEC;
   const bool rowok = need && iy >= 0 && iy < in_h;  // wave-uniform
-  const float* rp = pin + (long long)iy * in_w;
-  load_seg<VEC>(raw.prim, rp, rowok, a0, in_w);
+  const float* rp = pin + (long long)iy * in_rs;
+  load_seg<VEC>(raw.prim, rp, rowok, a0, in_w, lo, hi);
   if (lane < NX) {
-    load_seg<VEC>(raw.extra, rp, rowok, a0 + 64 * VEC, in_w);
+    load_seg<VEC>(raw.extra, rp, rowok, a0 + 64 * VEC, in_w, lo, hi);
   } else {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) raw.extra[e] = 0.f;
@@ -118,20 +128,27 @@ __device__ __forceinline__ void issue_row(RawRow<VEC>& raw, const float* __restr
 }
 
 template <int VEC>
-__device__ __forceinline__ void finish_row(Row<VEC>& r, const RawRow<VEC>& raw, int lane) {
+__device__ __forceinline__ void finish_row(Row<VEC>& r, const RawRow<VEC>& raw, int lane, unsigned pmask,
+                                           unsigned xmask) {
+  float prim[VEC], extra[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) r.v[e] = raw.prim[e];
+  for (int e = 0; e < VEC; ++e) {
+    prim[e] = (pmask >> e) & 1 ? raw.prim[e] : 0.f;
+    extra[e] = (xmask >> e) & 1 ? raw.extra[e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) r.v[e] = prim[e];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int e = VEC + j;
     const int d = e / VEC;   // lane distance of the segment holding column a0+e
     const int el = e % VEC;  // element inside that segment
-    const float t = (lane < d) ? raw.extra[el] : raw.prim[el];
+    const float t = (lane < d) ? extra[el] : prim[el];
     r.v[e] = __shfl(t, (lane + d) & 63, 64);
   }
 }
 
-template <int VEC>
+template <int VEC, bool NT = false>
 __device__ __forceinline__ void emit_row(float* __restrict__ pout, int oy, int oy_end, int out_w, int c0,
                                          const float (&kf)[4][4], const Row<VEC>& r0, const Row<VEC>& r1,
                                          const Row<VEC>& r2, const Row<VEC>& r3) {
@@ -154,7 +171,8 @@ __device__ __forceinline__ void emit_row(float* __restrict__ pout, int oy, int o
   if (c0 + VEC <= out_w) {
     if constexpr (VEC == 4) {
       f32x4_u t; t.x = acc[0]; t.y = acc[1]; t.z = acc[2]; t.w = acc[3];
-      *reinterpret_cast<f32x4_u*>(op) = t;
+      if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<f32x4_u*>(op));
+      else *reinterpret_cast<f32x4_u*>(op) = t;
     } else if constexpr (VEC == 2) {
       f32x2_u t; t.x = acc[0]; t.y = acc[1];
       *reinterpret_cast<f32x2_u*>(op) = t;
@@ -168,7 +186,7 @@ __device__ __forceinline__ void emit_row(float* __restrict__ pout, int oy, int o
   }
 }
 
-template <int VEC>
+template <int VEC, bool NT = false>
 __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict__ in, const float* __restrict__ kern,
                                                         float* __restrict__ out, const RMParams p) {
   const int lane = threadIdx.x & 63;
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
   const int a0 = c0 - p.pad_x0;
   const int oy0 = ty * p.th;
   const int oy_end = min(oy0 + p.th, p.out_h);
-  const float* pin = in + plane * (long long)p.in_h * p.in_w;
+  const float* pin = in + plane * p.in_plane_stride;
   float* pout = out + plane * (long long)p.out_h * p.out_w;
   const int iy0 = oy0 - p.pad_y0;
 
@@ -200,25 +218,36 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
   // while row r is filtered, rows r+1 and r+2 are on their way from HBM.
   Row<VEC> w0, w1, w2, w3;
   RawRow<VEC> ra, rb;
-#define ISSUE(raw, k, need) issue_row<VEC>(raw, pin, iy0 + (k), need, p.in_h, p.in_w, a0, lane)
+  // column-validity masks of this lane's primary / extra segment: the same for every row of the march
+  unsigned pmask = 0, xmask = 0;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    pmask |= (a0 + e >= 0 && a0 + e < p.in_w) ? 1u << e : 0u;
+    xmask |= (a0 + 64 * VEC + e >= 0 && a0 + 64 * VEC + e < p.in_w) ? 1u << e : 0u;
+  }
+  const float* lo = in;
+  const float* hi = in + ((long long)(p.planes - 1) * p.in_plane_stride + (long long)(p.in_h - 1) * p.in_row_stride + p.in_w);
+#define ISSUE(raw, k, need) issue_row<VEC>(raw, pin, iy0 + (k), need, p.in_h, p.in_w, p.in_row_stride, a0, lane, lo, hi)
+#define FINISH(w, raw) finish_row<VEC>(w, raw, lane, pmask, xmask)
   ISSUE(ra, 0, true); ISSUE(rb, 1, true);
-  finish_row<VEC>(w0, ra, lane); ISSUE(ra, 2, true);
-  finish_row<VEC>(w1, rb, lane); ISSUE(rb, 3, true);
-  finish_row<VEC>(w2, ra, lane); ISSUE(ra, 4, oy0 + 1 < oy_end);
+  FINISH(w0, ra); ISSUE(ra, 2, true);
+  FINISH(w1, rb); ISSUE(rb, 3, true);
+  FINISH(w2, ra); ISSUE(ra, 4, oy0 + 1 < oy_end);
   // invariant at loop top (r): w0..w2 = rows r..r+2; rb = row r+3 in flight, ra = row r+4 in flight
   for (int r = 0; r < p.th; r += 4) {
     const int oy = oy0 + r;
     if (oy >= oy_end) break;  // wave-uniform
-    finish_row<VEC>(w3, rb, lane); ISSUE(rb, r + 5, oy + 2 < oy_end);
-    emit_row<VEC>(pout, oy + 0, oy_end, p.out_w, c0, kf, w0, w1, w2, w3);
-    finish_row<VEC>(w0, ra, lane); ISSUE(ra, r + 6, oy + 3 < oy_end);
-    emit_row<VEC>(pout, oy + 1, oy_end, p.out_w, c0, kf, w1, w2, w3, w0);
-    finish_row<VEC>(w1, rb, lane); ISSUE(rb, r + 7, oy + 4 < oy_end && r + 4 < p.th);
-    emit_row<VEC>(pout, oy + 2, oy_end, p.out_w, c0, kf, w2, w3, w0, w1);
-    finish_row<VEC>(w2, ra, lane); ISSUE(ra, r + 8, oy + 5 < oy_end && r + 4 < p.th);
-    emit_row<VEC>(pout, oy + 3, oy_end, p.out_w, c0, kf, w3, w0, w1, w2);
+    FINISH(w3, rb); ISSUE(rb, r + 5, oy + 2 < oy_end);
+    emit_row<VEC, NT>(pout, oy + 0, oy_end, p.out_w, c0, kf, w0, w1, w2, w3);
+    FINISH(w0, ra); ISSUE(ra, r + 6, oy + 3 < oy_end);
+    emit_row<VEC, NT>(pout, oy + 1, oy_end, p.out_w, c0, kf, w1, w2, w3, w0);
+    FINISH(w1, rb); ISSUE(rb, r + 7, oy + 4 < oy_end && r + 4 < p.th);
+    emit_row<VEC, NT>(pout, oy + 2, oy_end, p.out_w, c0, kf, w2, w3, w0, w1);
+    FINISH(w2, ra); ISSUE(ra, r + 8, oy + 5 < oy_end && r + 4 < p.th);
+    emit_row<VEC, NT>(pout, oy + 3, oy_end, p.out_w, c0, kf, w3, w0, w1, w2);
   }
 #undef ISSUE
+#undef FINISH
 }
 
 // ---------------------------------------------------------------- path 2: plane-tile (f32, up=down=1, k<=4x4, small planes)
@@ -355,6 +384,7 @@ int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams
   RMParams r;
   r.planes = p.major; r.in_h = p.in_h; r.in_w = p.in_w; r.out_h = p.out_h; r.out_w = p.out_w;
   r.pad_x0 = p.pad_x0; r.pad_y0 = p.pad_y0; r.kh = p.kh; r.kw = p.kw;
+  r.in_plane_stride = p.in_plane_stride; r.in_row_stride = p.in_row_stride;
   const int vec = p.out_w >= 192 ? 4 : (p.out_w >= 96 ? 2 : 1);
   r.strips = (p.out_w + 64 * vec - 1) / (64 * vec);
   // Largest row tile that still leaves >= 32 waves per CU in the grid (halo re-read = 3/TH).
@@ -365,13 +395,17 @@ int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams
     if (waves >= want) break;
     th >>= 1;
   }
+  // outputs far larger than the 256 MiB Infinity Cache cannot be re-read from it by the consumer: store them
+  // non-temporal (measured +3 % on the 1 GB headline call); small layers keep the default policy.
+  const bool env_nt = (long long)p.major * p.out_h * p.out_w * 4 >= (512LL << 20);
   r.th = th;
   r.tiles_y = (p.out_h + th - 1) / th;
   r.total_waves = (long long)p.major * r.strips * r.tiles_y;
   const long long blocks = (r.total_waves + 3) / 4;
   if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
   const dim3 g((unsigned)blocks), b(256);
-  if (vec == 4) hipLaunchKernelGGL(ufd_rowmarch_f32<4>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
+  if (vec == 4 && env_nt) hipLaunchKernelGGL((ufd_rowmarch_f32<4, true>), g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
+  else if (vec == 4) hipLaunchKernelGGL(ufd_rowmarch_f32<4>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
   else if (vec == 2) hipLaunchKernelGGL(ufd_rowmarch_f32<2>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
   else hipLaunchKernelGGL(ufd_rowmarch_f32<1>, g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, r);
   return fmgan_check_launch();
@@ -379,7 +413,8 @@ int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams
 
 bool planetile_ok(int dtype, const UfdParams& p) {
   return dtype == FMGAN_F32 && p.minor == 1 && p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1 &&
-         p.kh <= 4 && p.kw <= 4 && (long long)p.in_h * p.in_w <= 12288 && (long long)p.out_h * p.out_w <= (1 << 20);
+         p.kh <= 4 && p.kw <= 4 && (long long)p.in_h * p.in_w <= 12288 && (long long)p.out_h * p.out_w <= (1 << 20) &&
+         p.in_row_stride == p.in_w && p.in_plane_stride == (long long)p.in_h * p.in_w;
 }
 
 int launch_planetile(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
@@ -399,7 +434,7 @@ int launch_planetile(const void* in, const void* kern, void* out, const UfdParam
 
 bool up2_ok(int dtype, const UfdParams& p) {
   return dtype == FMGAN_F32 && p.minor == 1 && p.up_x == 2 && p.up_y == 2 && p.down_x == 1 && p.down_y == 1 &&
-         p.kh <= 4 && p.kw <= 4;
+         p.kh <= 4 && p.kw <= 4 && p.in_row_stride == p.in_w && p.in_plane_stride == (long long)p.in_h * p.in_w;
 }
 
 int launch_up2(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
@@ -446,26 +481,30 @@ extern "C" int fmgan_upfirdn2d_select(int dtype, int major, int in_h, int in_w, 
                                       int pad_y1) {
   int st = validate(dtype, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y);
   if (st != FMGAN_OK) return st;
-  UfdParams p{major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, 0, 0};
+  UfdParams p{major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, 0, 0,
+              (long long)in_h * in_w * minor, in_w * minor};
   fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
                            &p.out_h, &p.out_w);
   if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
   return pick_path(dtype, p);
 }
 
-extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel, void* out, int major, int in_h,
-                               int in_w, int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x,
-                               int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int force_path,
-                               void* stream) {
+extern "C" int fmgan_upfirdn2d_strided(int dtype, const void* input, const void* kernel, void* out, int major,
+                                       int in_h, int in_w, int minor, long long in_plane_stride, int in_row_stride,
+                                       int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, int force_path, void* stream) {
   int st = validate(dtype, major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y);
   if (st != FMGAN_OK) return st;
-  UfdParams p{major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, 0, 0};
+  if (in_row_stride < in_w * minor || in_plane_stride < (long long)(in_h - 1) * in_row_stride + (long long)in_w * minor)
+    return FMGAN_EINVAL;
+  UfdParams p{major, in_h, in_w, minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, 0, 0,
+              in_plane_stride, in_row_stride};
   fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
                            &p.out_h, &p.out_w);
   if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
   if (major == 0) return FMGAN_OK;
   if (!input || !kernel || !out) return FMGAN_EINVAL;
-  if ((long long)in_h * in_w * minor > 0x7fffffffLL || (long long)p.out_h * p.out_w * minor > 0x7fffffffLL)
+  if ((long long)in_h * in_row_stride > 0x7fffffffLL || (long long)p.out_h * p.out_w * minor > 0x7fffffffLL)
     return FMGAN_EOVERFLOW;
   hipStream_t s = (hipStream_t)stream;
   int path = force_path;
@@ -487,4 +526,13 @@ extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel,
     default:
       return FMGAN_EUNSUPPORTED;
   }
+}
+
+extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel, void* out, int major, int in_h,
+                               int in_w, int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x,
+                               int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int force_path,
+                               void* stream) {
+  return fmgan_upfirdn2d_strided(dtype, input, kernel, out, major, in_h, in_w, minor, (long long)in_h * in_w * minor,
+                                 in_w * minor, kernel_h, kernel_w, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                                 pad_y1, force_path, stream);
 }

@@ -40,12 +40,13 @@ def lib():
     _sig(L.fmgan_upfirdn2d_select, [i] * 15)
     _sig(L.fmgan_upfirdn2d_out_size, [i] * 12 + [ctypes.POINTER(i)] * 2)
     _sig(L.fmgan_upfirdn2d, [i, vp, vp, vp] + [i] * 15 + [vp])
+    _sig(L.fmgan_upfirdn2d_strided, [i, vp, vp, vp] + [i] * 4 + [ll, i] + [i] * 11 + [vp])
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
-    _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, vp, ll, vp])
+    _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
     if L.fmgan_abi_version() != 1:
         raise RuntimeError('libfmgan_hip.so ABI version mismatch')
@@ -143,6 +144,21 @@ def upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
     return out
 
 
+def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_stride, kernel, pad_x0, pad_x1, pad_y0, pad_y1):
+    """up=down=1 FIR of a strided f32 input [major, in_h, in_w] (see aligned_rows_buffer) -> contiguous [major,out_h,out_w]."""
+    k = kernel.contiguous()
+    kh, kw = k.shape
+    out_h, out_w = upfirdn2d_out_size(in_h, in_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1)
+    out = torch.empty((major, out_h, out_w), dtype=torch.float32, device=device)
+    with on_device(out) as stream:
+        tok = _observer.begin('upfirdn2d', (major, in_h, in_w, out_h, out_w, 1, 1, 4))
+        check(lib().fmgan_upfirdn2d_strided(F32, in_ptr, ptr(k), ptr(out), major, in_h, in_w, 1, plane_stride,
+                                            row_stride, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, -1, stream),
+              'upfirdn2d_strided')
+        _observer.end(tok)
+    return out
+
+
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     """Same positional signature as the reference's pybind `fused_bias_act` (op/fused_bias_act.cpp:11-21);
     empty `bias` / `refer` tensors mean "absent" (op/fused_bias_act_kernel.cu:62-63)."""
@@ -204,24 +220,42 @@ def modconv_weight_prep(weight, scale):
     return wt
 
 
+def aligned_rows_buffer(b, c, oh, ow, pad0, device):
+    """Private conv_transpose -> blur intermediate: rows padded to a multiple of 32 floats (one 128-byte line) and
+    shifted right by pad0 (mod 4) floats, so that the blur's first tap column (x = -pad0) sits on a 16-byte boundary
+    and every wave-wide 1 KiB row load covers exactly 8 cache lines.  Measured on the 1024^2 blur (MI355X):
+    contiguous 2W+1 rows 512-527 us, 16-byte-aligned rows 498 us, line-aligned rows 438-450 us (= copy speed).
+    Returns (storage, data_ptr of logical element (0,0,0,0), plane stride, row stride) — strides in elements."""
+    off = pad0 % 4
+    rs = (ow + off + 31) // 32 * 32
+    buf = torch.empty((b * c, oh, rs), dtype=torch.float32, device=device)
+    return buf, buf.data_ptr() + 4 * off, oh * rs, rs
+
+
 def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=None, fuse_act=False, alpha=0.2,
-              act_scale=2 ** 0.5):
-    """x [B,cin,H,W] f32, wt from modconv_weight_prep (3x3), style [B,cin], demod [B,cout] or None."""
+              act_scale=2 ** 0.5, strided_out=None):
+    """x [B,cin,H,W] f32, wt from modconv_weight_prep (3x3), style [B,cin], demod [B,cout] or None.
+    strided_out = (ptr, plane_stride, row_stride) writes into a caller-owned strided buffer and returns None."""
     require_gpu(x, 'input')
     x = x.contiguous()
     style = style.contiguous()
     b, cin, h, w = x.shape
     cout = wt.shape[2]
     oh, ow = (2 * h + 1, 2 * w + 1) if mode == 1 else (h, w)
-    out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=x.device)
+    if strided_out is None:
+        out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=x.device)
+        out_ptr, ops, ors = out.data_ptr(), 0, 0
+    else:
+        out = None
+        out_ptr, ops, ors = strided_out
     nz = noise.contiguous() if noise is not None else None
     ws_bytes = lib().fmgan_modconv2d_workspace_bytes(b, cin, cout, h, w, mode)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with on_device(x) as stream:
         tok = _observer.begin('modconv2d', (b, cin, cout, h, w, mode))
-        check(lib().fmgan_modconv2d_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), ptr(out), b, cin, cout, h, w, mode,
+        check(lib().fmgan_modconv2d_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), out_ptr, b, cin, cout, h, w, mode,
                                         ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
-                                        int(bool(fuse_act)), float(alpha), float(act_scale), ptr(ws), ws_bytes,
+                                        int(bool(fuse_act)), float(alpha), float(act_scale), ops, ors, ptr(ws), ws_bytes,
                                         stream), 'modconv2d')
         _observer.end(tok)
     return out

@@ -255,7 +255,15 @@ class StyledConv(nn.Module):
         if noise is None:
             noise = input.new_empty(b, 1, oh, ow).normal_()
         if conv.upsample:
-            out = conv.blur(_native.modconv2d(input, conv.mfma_weight(), s, demod, 1))
+            # private intermediate [B,C,2H+1,2W+1] in the aligned-row layout: every dwordx4 load of the blur is
+            # 16-byte aligned (the contiguous 2W+1-float rows never are)
+            c = conv.out_channel
+            pad0, pad1 = conv.blur.pad
+            buf, p0, ps, rs = _native.aligned_rows_buffer(b, c, 2 * h + 1, 2 * w + 1, pad0, input.device)
+            _native.modconv2d(input, conv.mfma_weight(), s, demod, 1, strided_out=(p0, ps, rs))
+            out = _native.upfirdn2d_strided(p0, input.device, b * c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
+                                            pad0, pad1, pad0, pad1).view(b, c, oh, ow)
+            del buf
             out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)
         else:
             out = _native.modconv2d(input, conv.mfma_weight(), s, demod, 0, noise=noise,

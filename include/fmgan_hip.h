@@ -84,6 +84,21 @@ int fmgan_upfirdn2d(int dtype, const void *input, const void *kernel, void *out,
                     int force_path, void *stream);
 
 /*
+ * Same op on a row/plane-strided input (minor must be 1 when strides are not the contiguous ones):
+ * element (n, y, x) of the input lives at input[n*in_plane_stride + y*in_row_stride + x] (strides in elements).
+ * Used for the private conv_transpose -> blur intermediate of ModulatedConv2d(upsample) (stylegan2.py:276-279):
+ * its rows are 2W+1 floats, never 16-byte aligned when contiguous; with row stride round_up(2W+2, 4) and a
+ * one-float left offset every dwordx4 load of the blur is aligned (4.08 -> 4.8 TB/s on the 1024^2 layer).
+ */
+int fmgan_upfirdn2d_strided(int dtype, const void *input, const void *kernel, void *out,
+                            int major, int in_h, int in_w, int minor,
+                            long long in_plane_stride, int in_row_stride,
+                            int kernel_h, int kernel_w,
+                            int up_x, int up_y, int down_x, int down_y,
+                            int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                            int force_path, void *stream);
+
+/*
  * fused_bias_act: out[i] = act'(x[i] + bias[(i / step_b) % size_b]; refer[i]) * scale
  *   act*10+grad: 10,11 linear; 12 zero; 30 lrelu(x); 31 (refer>0 ? x : alpha*x); 32 zero
  *   (op/fused_bias_act_kernel.cu:36-45).  bias == NULL or size_b == 0: no bias;
@@ -139,6 +154,8 @@ int fmgan_modconv_weight_prep_f32(const float *weight, float *wt, int cout, int 
  *   out = lrelu( (conv + noise_weight[0]*noise[b or 0,y,x]) + bias[o] ) * act_scale
  *   noise [noise_batch (1 or batch), h*w] or NULL, noise_weight device scalar or NULL, bias [cout] or NULL.
  * The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).
+ * out_plane_stride / out_row_stride (elements; 0 = contiguous): element (b,o,y,x) is written to
+ *   out[(b*cout+o)*out_plane_stride + y*out_row_stride + x] — see fmgan_upfirdn2d_strided.
  * workspace: tiny layers (4x4..32x32 at small batch) have too few output tiles to fill 256 CUs, so the
  *   input-channel loop is split over blocks (split-K) and the partial sums are combined by a finish kernel.
  *   Pass a device buffer of at least fmgan_modconv2d_workspace_bytes() bytes (0 = no split for this shape);
@@ -151,6 +168,7 @@ int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
                         int batch, int cin, int cout, int h, int w, int mode,
                         const float *noise, const float *noise_weight, const float *bias,
                         int noise_batch, int fuse_act, float alpha, float act_scale,
+                        long long out_plane_stride, int out_row_stride,
                         void *workspace, long long workspace_bytes, void *stream);
 
 /*

@@ -62,8 +62,8 @@ def test_invalid_arguments_return_status_without_gpu():
     assert L.fmgan_upfirdn2d(0, None, None, None, 1, 8, 8, 1, 4, 4, 0, 1, 1, 1, 1, 1, 1, 1, -1, None) == -1
     assert L.fmgan_fused_bias_act(0, None, None, None, None, 16, 0, 1, 3, 0, 0.2, 1.4, None) == -1
     assert L.fmgan_fused_bias_act(9, None, None, None, None, 16, 0, 1, 3, 0, 0.2, 1.4, None) == -2
-    assert L.fmgan_modconv2d_f32(None, None, None, None, None, 1, 8, 8, 4, 4, 3, None, None, None, 1, 0, 0.2, 1.4, None, 0, None) == -2
-    assert L.fmgan_modconv2d_f32(None, None, None, None, None, 1, 8, 8, 4, 4, 0, None, None, None, 1, 0, 0.2, 1.4, None, 0, None) == -1
+    assert L.fmgan_modconv2d_f32(None, None, None, None, None, 1, 8, 8, 4, 4, 3, None, None, None, 1, 0, 0.2, 1.4, 0, 0, None, 0, None) == -2
+    assert L.fmgan_modconv2d_f32(None, None, None, None, None, 1, 8, 8, 4, 4, 0, None, None, None, 1, 0, 0.2, 1.4, 0, 0, None, 0, None) == -1
     assert L.fmgan_torgb_f32(None, None, None, None, None, None, 1, 8, 5, 16, 1.0, None) == -1
     # split-K workspace query is pure host logic: tiny layer -> non-zero, big layer -> 0
     assert L.fmgan_modconv2d_workspace_bytes(8, 512, 512, 4, 4, 0) > 0

@@ -93,6 +93,43 @@ def test_upfirdn2d_rowmarch_vs_c_oracle(shape, kernel, pad):
     np.testing.assert_allclose(y0.cpu().numpy().reshape(ref.shape), ref, **OP_TOL)
 
 
+@pytest.mark.parametrize('shape,pad', [((3, 129, 129), (1, 1)), ((2, 65, 65), (1, 1)), ((2, 257, 300), (2, 2)),
+                                       ((5, 9, 9), (1, 1)), ((1, 1025, 1025), (1, 1))])
+def test_upfirdn2d_strided_input_matches_contiguous(shape, pad):
+    """The aligned-row layout of the private conv_transpose -> blur intermediate (row stride padded to 4 floats,
+    pad0 floats of left offset) must give bit-identical results to the contiguous tensor."""
+    from op import _native
+    n, h, w = shape
+    k = cases.make_fir(('rand', 4, 4, 51)).to(dev())
+    x = synth.tensor(f'strided/{shape}', shape).to(dev())
+    ref = _native.upfirdn2d(x.reshape(n, h, w, 1), k, 1, 1, 1, 1, pad[0], pad[1], pad[0], pad[1])
+    buf, p0, ps, rs = _native.aligned_rows_buffer(n, 1, h, w, pad[0], dev())
+    buf.fill_(float('nan'))                      # the padding must never leak into the result
+    off = pad[0] % 4
+    buf[:, :, off:off + w] = x
+    assert p0 == buf.data_ptr() + 4 * off and rs % 32 == 0
+    y = _native.upfirdn2d_strided(p0, dev(), n, h, w, ps, rs, k, pad[0], pad[1], pad[0], pad[1])
+    assert torch.equal(y, ref.view_as(y))
+
+
+def test_modconv_strided_output_matches_contiguous():
+    from op import _native
+    for (b, cin, cout, h, w) in ((2, 8, 40, 16, 16), (1, 16, 130, 9, 7), (9, 12, 20, 4, 4)):
+        x = synth.tensor(f'so/{cout}/x', (b, cin, h, w)).to(dev())
+        wgt = synth.tensor(f'so/{cout}/w', (cout, cin, 3, 3)).to(dev())
+        s = synth.tensor(f'so/{cout}/s', (b, cin), shift=1.0, scale=0.5).to(dev())
+        scale = 1.0 / (cin * 9) ** 0.5
+        wt = _native.modconv_weight_prep(wgt, scale)
+        dm = _native.modconv_demod(wgt, s, scale)
+        ref = _native.modconv2d(x, wt, s, dm, 1)
+        oh, ow = 2 * h + 1, 2 * w + 1
+        buf, p0, ps, rs = _native.aligned_rows_buffer(b, cout, oh, ow, 1, dev())
+        buf.fill_(float('nan'))
+        _native.modconv2d(x, wt, s, dm, 1, strided_out=(p0, ps, rs))
+        assert torch.equal(buf[:, :, 1:1 + ow].reshape(b, cout, oh, ow), ref)
+        assert torch.isnan(buf[:, :, 0]).all() and torch.isnan(buf[:, :, 1 + ow:]).all()
+
+
 def test_upfirdn2d_many_planes_and_minor():
     """major > 16384 (the reference's loop_major path, op/upfirdn2d_kernel.cu:296) and minor > 1 (generic kernel)."""
     from op import _native
