@@ -30,14 +30,18 @@ def init_distributed(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        local = local % torch.cuda.device_count()     # rehearsals with more ranks than GPUs share devices (gloo only)
+    backend = backend or os.environ.get('FMGAN_DIST_BACKEND')
     device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not _active():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        kw = {'device_id': device} if use_gpu else {}
-        dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world, **kw)
+        backend = backend or ('nccl' if use_gpu else 'gloo')
+        kw = {'device_id': device} if (use_gpu and backend == 'nccl') else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, device
 
 

@@ -7,6 +7,7 @@ Image/PIL helpers of the reference file (torchvision-based) are not on the path 
 import torch
 
 from stylegan2 import Generator
+from Util.streams import side_streams, run_on
 
 MODULATION_ENCODING = ['Render Image', 'Photo Image']
 CO_MODULATION_MODE = ['Multiplication', 'Concatenation', 'Tensor Transform']
@@ -44,23 +45,32 @@ def Forward_Inference_3_Encoder(p_input, r_input, E_Tsr, E_W, E_W_Plus, g_ema, t
     tsr = E_Tsr(photo | render) [N,512,4,4];  W = E_W(render) [N,512];  W+ = E_W_Plus(photo) [N,n_latent,512];
     latent[:, i] = W * W+[:, i] for i in sliced_layer else W;  image = g_ema(latent, external_input_tensor=tsr).
     """
-    if tsr_encode == 'Photo Image':
-        encoded_tensor = E_Tsr(p_input)
-    elif tsr_encode == 'Render Image':
-        encoded_tensor = E_Tsr(r_input)
-    else:
+    if tsr_encode not in MODULATION_ENCODING:
         raise ValueError(f'tsr_encode must be one of {MODULATION_ENCODING}')
-    encoded_W = E_W(r_input)
-    encoded_W_plus = E_W_Plus(p_input)
+    tsr_input = p_input if tsr_encode == 'Photo Image' else r_input
+    if p_input.is_cuda and not torch.is_grad_enabled():
+        # the three encoders are independent: the two small ResNets run on side streams beside the pSp encoder
+        s1, s2 = side_streams(p_input.device, 2)
+        join1, encoded_tensor = run_on(s1, E_Tsr, tsr_input)
+        join2, encoded_W = run_on(s2, E_W, r_input)
+        encoded_W_plus = E_W_Plus(p_input)
+        join1(); join2()
+    else:
+        encoded_tensor = E_Tsr(tsr_input)
+        encoded_W = E_W(r_input)
+        encoded_W_plus = E_W_Plus(p_input)
 
     n_styles = encoded_W_plus.shape[1]
     if sliced_layer is None:
         sliced_layer = range(_unwrapped(g_ema).n_latent)
-    mask = torch.zeros(n_styles, dtype=torch.bool)
-    mask[[i for i in sliced_layer if i < n_styles]] = True
-    # W (.) W+ where sliced, W elsewhere — one broadcast op instead of a Python loop + stack + transpose
-    w_b = encoded_W.unsqueeze(1)
-    encoded_latent = torch.where(mask.view(1, -1, 1).to(w_b.device), w_b * encoded_W_plus, w_b.expand_as(encoded_W_plus))
+    sliced = {i for i in sliced_layer if 0 <= i < n_styles}
+    # W (.) W+ where sliced, W elsewhere.  Built from device tensors only (no host-side mask upload), so the whole
+    # forward stays capturable in a HIP graph.
+    if len(sliced) == n_styles:
+        encoded_latent = encoded_W.unsqueeze(1) * encoded_W_plus
+    else:
+        encoded_latent = torch.stack([encoded_W * encoded_W_plus[:, i] if i in sliced else encoded_W
+                                      for i in range(n_styles)], 1)
 
     g_output = g_ema(noise_z=None, latent_styles=[encoded_latent], input_is_latent=True,
                      use_external_input_tensor=True, external_input_tensor=encoded_tensor,

@@ -18,6 +18,7 @@ from torch.nn import functional as F
 
 from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from op import _native, modconv
+from Util.streams import side_streams, run_on
 
 _SQRT2 = math.sqrt(2.0)
 
@@ -404,8 +405,22 @@ class Generator(nn.Module):
                 return y
             return layer(x, w, **kw)
 
+        # Inference: the RGB branch (ToRGB + skip upsample, HBM-bound) of resolution r has no consumer until the
+        # image is returned, so it runs on a side stream beside the MFMA-bound convs of resolution 2r.
+        overlap = out.is_cuda and not torch.is_grad_enabled() and not return_style_scalars
+        joins = []
+
+        def rgb(layer, x, w, skip):
+            if not overlap:
+                return layer(x, w, skip)
+            join, y = run_on(side, layer, x, w, skip)
+            joins.append(join)
+            return y
+
+        if overlap:
+            side, = side_streams(out.device, 1)
         out = run(self.conv1, out, latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        skip = rgb(self.to_rgb1, out, latent[:, 1], None)
         rgbs = [skip]
         for blk, to_rgb in enumerate(self.to_rgbs):
             i = 1 + 2 * blk
@@ -414,8 +429,13 @@ class Generator(nn.Module):
             if return_style_scalars and i + 3 == latent.shape[1]:   # style scalars of the last ToRGB only (:660-662)
                 skip = run(to_rgb, out, latent[:, i + 2], skip=skip)
             else:
-                skip = to_rgb(out, latent[:, i + 2], skip)
+                skip = rgb(to_rgb, out, latent[:, i + 2], skip)
             rgbs.append(skip)
+        for join in joins[-1:]:
+            join()                      # the side stream is in order: joining its last launch joins all of them
+        for r in rgbs[:-1]:
+            if overlap:
+                r.record_stream(torch.cuda.current_stream(out.device))
         image = skip
 
         if PPL_regularize:

@@ -90,10 +90,14 @@ def make_step(nets, batch, device, rank):
     photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)     # resident in HBM before timing
     render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
 
-    def step():
+    def forward(p, r):
         with torch.no_grad():
-            return Forward_Inference_3_Encoder(photo, render, nets['e_tsr'], nets['e_w'], nets['e_wp'], nets['g'])
+            return Forward_Inference_3_Encoder(p, r, nets['e_tsr'], nets['e_w'], nets['e_wp'], nets['g'])
 
+    def step():
+        return forward(photo, render)
+
+    step.forward = forward
     return step, (photo, render)
 
 
@@ -111,7 +115,8 @@ def timed(step, steps, warmup, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     return dt
@@ -166,6 +171,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='pairs per GPU (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='also time a HIP-graph replay of the forward and report it as '
+                    'value (measured: no gain at these sizes, the step is GPU-bound)')
     args = ap.parse_args()
 
     from Miscellaneous import distributed as D
@@ -187,8 +194,14 @@ def main():
     for _ in range(args.warmup):
         step()
     _native.set_observer(timer)
-    dt = timed(step, args.steps, 0, world)
+    dt_eager = timed(step, args.steps, 0, world)      # eager launches; the headline kernel is bracketed by HIP events
     _native.set_observer(None)
+    dt = dt_eager
+    graphed = None
+    if args.graph:
+        from Util.hip_graph import GraphedForward
+        graphed = GraphedForward(step.forward, inputs)
+        dt = timed(lambda: graphed(*inputs), args.steps, 2, world)   # the same forward, replayed as one HIP graph
     pairs_per_s = world * batch * args.steps / dt
 
     out = {
@@ -196,7 +209,9 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
-                   'image_size': wl['size'], 'parallelism': f'replicas x{world} (batch-sharded, no collective)'},
+                   'image_size': wl['size'], 'parallelism': f'replicas x{world} (batch-sharded, no collective)',
+                   'launch': 'eager' if graphed is None else 'hip-graph replay of the whole forward'},
+        'eager': {'value': world * batch * args.steps / dt_eager, 'ms_per_step': 1e3 * dt_eager / args.steps},
     }
 
     # roofline of the dominant HBM kernel (upfirdn2d headline call), algorithmic bytes = 4*(in + out)
@@ -237,8 +252,13 @@ def main():
         torch.cuda.empty_cache()
         wl2 = WORKLOADS['pairs256']
         nets2 = build_models(wl2['size'], device)
-        step2, _ = make_step(nets2, wl2['batch'], device, rank)
-        dt2 = timed(step2, args.steps, args.warmup, world)
+        step2, in2 = make_step(nets2, wl2['batch'], device, rank)
+        if not args.graph:
+            dt2 = timed(step2, args.steps, args.warmup, world)
+        else:
+            g2 = GraphedForward(step2.forward, in2)
+            dt2 = timed(lambda: g2(*in2), args.steps, 2, world)
+            del g2
         out['pairs_per_s_256'] = world * wl2['batch'] * args.steps / dt2
         out['ms_per_step_256'] = 1e3 * dt2 / args.steps
         out['config']['secondary'] = f"pairs256: {wl2['desc']}"
@@ -247,6 +267,7 @@ def main():
         nets = build_models(wl['size'], device)
         _, inputs = make_step(nets, 1, device, rank)
 
+    del graphed
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(nets, inputs, wl['size'])
     if rank == 0:
