@@ -7,7 +7,7 @@ Image/PIL helpers of the reference file (torchvision-based) are not on the path 
 import torch
 
 from stylegan2 import Generator
-from Util.streams import side_streams, run_on
+from Util.streams import side_streams, run_on, overlap_ok
 
 MODULATION_ENCODING = ['Render Image', 'Photo Image']
 CO_MODULATION_MODE = ['Multiplication', 'Concatenation', 'Tensor Transform']
@@ -48,7 +48,7 @@ def Forward_Inference_3_Encoder(p_input, r_input, E_Tsr, E_W, E_W_Plus, g_ema, t
     if tsr_encode not in MODULATION_ENCODING:
         raise ValueError(f'tsr_encode must be one of {MODULATION_ENCODING}')
     tsr_input = p_input if tsr_encode == 'Photo Image' else r_input
-    if p_input.is_cuda and not torch.is_grad_enabled():
+    if overlap_ok(p_input):
         # the three encoders are independent: the two small ResNets run on side streams beside the pSp encoder
         s1, s2 = side_streams(p_input.device, 2)
         join1, encoded_tensor = run_on(s1, E_Tsr, tsr_input)

@@ -6,9 +6,16 @@ side streams so the hardware can co-schedule them (two processes sharing one MI3
 the headroom this recovers inside one process).  Fork/join are stream waits only — no host synchronisation — so the
 forward stays capturable in a HIP graph.
 """
+import os
+
 import torch
 
 _POOL = {}
+ENABLED = os.environ.get('FMGAN_NO_OVERLAP', '0') != '1'   # set False (or FMGAN_NO_OVERLAP=1) for single-stream issue
+
+
+def overlap_ok(t):
+    return ENABLED and t.is_cuda and not torch.is_grad_enabled()
 
 
 def side_streams(device, n):

@@ -18,7 +18,7 @@ from torch.nn import functional as F
 
 from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from op import _native, modconv
-from Util.streams import side_streams, run_on
+from Util.streams import side_streams, run_on, overlap_ok
 
 _SQRT2 = math.sqrt(2.0)
 
@@ -407,7 +407,7 @@ class Generator(nn.Module):
 
         # Inference: the RGB branch (ToRGB + skip upsample, HBM-bound) of resolution r has no consumer until the
         # image is returned, so it runs on a side stream beside the MFMA-bound convs of resolution 2r.
-        overlap = out.is_cuda and not torch.is_grad_enabled() and not return_style_scalars
+        overlap = overlap_ok(out) and not return_style_scalars
         joins = []
 
         def rgb(layer, x, w, skip):

@@ -220,9 +220,16 @@ def main():
         ms, n = summ[('upfirdn2d', head)]
         bytes_alg = 4.0 * head[0] * (head[1] * head[2] + head[3] * head[4])
         ach = bytes_alg / (ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, 'profiles', 'r01_headline_traffic.json')
+        if batch == wl['batch'] and args.workload == 'pairs1024' and os.path.exists(tf):
+            rec = json.load(open(tf))       # PMC passes cannot run inside this process: committed rocprofv3 result
+            traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/r01_headline_traffic.json (' + rec['source'] + ')'
+
         out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_rowmarch_f32<4> [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                           'traffic': None, 'avg_launch_ms': ms, 'launches': n, 'algorithmic_bytes': bytes_alg}
+                           'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': ms, 'launches': n,
+                           'algorithmic_bytes': bytes_alg}
 
     # per-kernel breakdown (separate, fully instrumented pass; not part of `value`)
     full = LaunchTimer(lambda name, info: True)

@@ -198,3 +198,50 @@ def test_discriminator_r1_penalty_vs_oracle():
     np.testing.assert_allclose(r1_d.item(), r1_o.item(), rtol=1e-3)
     ref = gw_o.numpy()
     np.testing.assert_allclose(gw_d.cpu().numpy(), ref, atol=2e-3 * np.abs(ref).max(), rtol=2e-3)
+
+
+def test_overlapped_and_graphed_forward_equal_serial():
+    """Inference issues the ResNet encoders and the RGB branch on side streams, and the whole forward can be replayed
+    from a HIP graph.  The Generator (this repo's kernels: no atomics, fixed summation order) must be bit-identical
+    run to run, overlapped or not, graphed or not; the full path is compared to tolerance because MIOpen's encoder
+    convolutions are themselves not bit-reproducible run to run (measured 2e-6 on identical inputs)."""
+    import stylegan2
+    from Util import streams
+    from Util.network_util import Forward_Inference_3_Encoder
+    from Util.hip_graph import GraphedForward
+    e_tsr, e_w, e_wp = _encoders(10)
+    G = _load(stylegan2.Generator(64, 512, 2), 'generator', 4)
+    p = synth.tensor('ovl/photo', (2, 3, 256, 256), dist='uniform').to(dev())
+    r = synth.tensor('ovl/render', (2, 3, 256, 256), dist='uniform').to(dev())
+    lat = synth.tensor('ovl/lat', (2, G.n_latent, 512)).to(dev())
+    tsr = synth.tensor('ovl/tsr', (2, 512, 4, 4)).to(dev())
+    wrap = _PinNoise(G)
+
+    def gen(l, t):
+        with torch.no_grad():
+            return G(None, latent_styles=[l], input_is_latent=True, use_external_input_tensor=True,
+                     external_input_tensor=t, randomize_noise=False)
+
+    def fwd(a, b):
+        with torch.no_grad():
+            return Forward_Inference_3_Encoder(a, b, e_tsr, e_w, e_wp, wrap)
+
+    try:
+        streams.ENABLED = False
+        g_serial = gen(lat, tsr).clone()
+        f_serial = fwd(p, r).clone()
+    finally:
+        streams.ENABLED = True
+    g_overlap = gen(lat, tsr).clone()
+    assert torch.equal(g_overlap, g_serial)
+    for _ in range(3):
+        assert torch.equal(gen(lat, tsr), g_serial)           # no race: repeated overlapped runs are bit-identical
+    gg = GraphedForward(gen, (lat, tsr))
+    for _ in range(3):
+        assert torch.equal(gg(lat, tsr), g_serial)
+    lat2 = synth.tensor('ovl/lat2', (2, G.n_latent, 512)).to(dev())
+    assert torch.equal(gg(lat2, tsr), gen(lat2, tsr))          # new inputs are copied into the static buffers
+    tol = dict(atol=1e-4 * float(f_serial.abs().max()), rtol=1e-4)
+    torch.testing.assert_close(fwd(p, r), f_serial, **tol)
+    gf = GraphedForward(fwd, (p, r))
+    torch.testing.assert_close(gf(p, r), f_serial, **tol)
