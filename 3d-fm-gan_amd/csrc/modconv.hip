@@ -399,11 +399,17 @@ __global__ __launch_bounds__(256) void modconv_splitk_finish_f32(const MCParams 
   }
 }
 
-inline int pick_tw_log2(int gw) { return gw <= 4 ? 2 : (gw <= 8 ? 3 : (gw <= 16 ? 4 : 5)); }
+// Tile width.  Thin column segments of small images use 1- or 2-wide tiles (fewer, fuller blocks: 220 vs 284 us on the
+// 16^2 -> 32^2 layer); on large images the taller patch would overflow the prefetch slots and fall to the
+// synchronous staging path (+15 %), so they keep 4-wide tiles.
+inline int pick_tw_log2(int gw, int gh) {
+  if (gh <= 32 && gw <= 2) return gw <= 1 ? 0 : 1;
+  return gw <= 4 ? 2 : (gw <= 8 ? 3 : (gw <= 16 ? 4 : 5));
+}
 
 // tile plan of one segment; returns its block count (without the o_tiles factor) and LDS floats for the patch
 inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
-  sg.tw_log2 = pick_tw_log2(sg.gw);
+  sg.tw_log2 = pick_tw_log2(sg.gw, sg.gh);
   const int TW = 1 << sg.tw_log2;
   const int rows_total = BN / TW;
   int th = rows_total, nb = 1;
@@ -469,19 +475,41 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
   return cfg == 1 ? launch_cfg<1, 2, 1, 1, 4>(p, s) : launch_cfg<1, 1, 2, 1, 4>(p, s);
 }
 
-// split-K factor so that a tiny layer still fills the chip; 1 when the layer already has enough blocks
-inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
-  const long long positions = (long long)batch * h * w;
-  const int cfg = pick_cfg(mode, cout, positions);
+// Blocks of one launch (all segments), for a given tile configuration.
+inline long long count_blocks(int mode, int cfg, int batch, int cout, int h, int w) {
   int BM, BN;
   cfg_dims(mode, cfg, BM, BN);
-  const long long blocks = ((cout + BM - 1) / BM) * ((positions + BN - 1) / BN);
+  MCParams::Seg sg[3] = {{0, 0, h, w}, {h, 0, 1, w + 1}, {0, w, h, 1}};   // any order: only the sum matters
+  long long blocks = 0;
+  for (int i = 0; i < (mode == 1 ? 3 : 1); ++i) blocks += plan_segment(sg[i], batch, BN);
+  return blocks * ((cout + BM - 1) / BM);
+}
+
+// Split-K factor.  A launch runs in rounds of `slots` co-resident blocks; 608 equal blocks on 512 slots take two
+// rounds, i.e. 1.7x their ideal time.  Splitting the input-channel loop ks ways makes the blocks ks times shorter
+// (plus a fixed prologue/epilogue per block and a finish pass over ks partial slabs).  Pick the ks that minimises
+// the modelled time; layers with many rounds keep ks = 1.
+inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
+  const int cfg = pick_cfg(mode, cout, (long long)batch * h * w);
+  const long long blocks = count_blocks(mode, cfg, batch, cout, h, w);
   const int chunks = (cin + MC_KC - 1) / MC_KC;
-  if (blocks >= 384 || chunks < 8) return 1;
-  int ks = (int)((768 + blocks - 1) / blocks);
-  if (ks > 16) ks = 16;
-  if (ks > chunks / 2) ks = chunks / 2;
-  return ks < 2 ? 1 : ks;
+  const int slots = FMGAN_NUM_CU * ((mode == 0 && cfg == 3) ? 4 : 2);   // co-resident blocks (VGPR-limited)
+  if (blocks >= 4LL * slots || chunks < 4) return 1;
+  int BM, BN;
+  cfg_dims(mode, cfg, BM, BN);
+  // time unit: one chunk of one block.  Finish pass: (2*ks + 1) * out_bytes at ~4 TB/s against ~5 us per full-size chunk
+  const double mfma_per_chunk = (double)(BM / 32) * (BN / 32) * (mode == 1 ? 9 : 9) * (MC_KC / 2) / 4.0;  // per wave
+  const double t_chunk_us = mfma_per_chunk * 64.0 / 2360.0 * 2.0;       // two blocks share each SIMD
+  const double out_mb = (double)batch * cout * (mode == 1 ? (2.0 * h + 1) * (2.0 * w + 1) : (double)h * w) * 4e-6;
+  int best = 1;
+  double best_t = 1e30;
+  for (int ks = 1; ks <= 16 && ks <= chunks / 2; ++ks) {
+    const long long rounds = (blocks * ks + slots - 1) / slots;
+    double t = (double)rounds * ((double)((chunks + ks - 1) / ks) + 2.0) * t_chunk_us;
+    if (ks > 1) t += (2.0 * ks + 1.0) * out_mb / 4.0 + 3.0;   // MB / (4 MB per us) + launch
+    if (t < best_t * 0.97) { best_t = t; best = ks; }
+  }
+  return best;
 }
 
 // ------------------------------------------------------------------ ToRGB (1x1, <= 4 output channels, HBM-bound)
@@ -605,15 +633,18 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
   p.ws = (float*)workspace;
   const int chunks = (cin + MC_KC - 1) / MC_KC;
   p.cin_per_split = ((chunks + p.ksplit - 1) / p.ksplit) * MC_KC;
-  // segment 0: the h x w grid.  Mode 1: quads (2m+py, 2n+px) of m < h, n < w cover Y < 2h, X < 2w; the last
+  // Main segment: the h x w grid.  Mode 1: quads (2m+py, 2n+px) of m < h, n < w cover Y < 2h, X < 2w; the last
   // output row (m = h) and column (n = w) are two thin segments of the same launch, so they run beside the
   // main tiles instead of serialising their own latency-bound K loops.
-  p.seg[0] = {0, 0, h, w};
-  p.nseg = 1;
+  // The thin segments come FIRST in block order: their blocks pack few useful outputs and must not be the tail.
   if (mode == 1) {
-    p.seg[1] = {h, 0, 1, w + 1};
-    p.seg[2] = {0, w, h, 1};
+    p.seg[0] = {h, 0, 1, w + 1};
+    p.seg[1] = {0, w, h, 1};
+    p.seg[2] = {0, 0, h, w};
     p.nseg = 3;
+  } else {
+    p.seg[0] = {0, 0, h, w};
+    p.nseg = 1;
   }
   int st = launch_any(mode, cfg, p, s);
   if (st != FMGAN_OK) return st;
