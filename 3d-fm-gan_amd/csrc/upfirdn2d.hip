@@ -13,11 +13,19 @@
 //    marches it down TH output rows: one dword-aligned global_load_dwordx4 per lane per input row
 //    (1 KiB contiguous per wave-instruction), the 3 halo columns come from the neighbouring lane
 //    by wave shuffle, the 4-row vertical window lives in registers (rolling, statically unrolled
-//    by 4) and the 16 taps sit in SGPRs.  Every input row is read once per row-tile ((TH+3)/TH
-//    amplification, halo rows are L2/MALL hits thanks to the XCD-contiguous block order) and every
-//    output row is written once with dwordx4 stores.
-//  * Path 2 ("plane-tile") stages whole small planes (<= 65x65) in LDS with flat coalesced loads:
-//    at 4..64 px the planes are too narrow for a wave-wide strip.
+//    by 4, two row-loads in flight ahead of the row being filtered) and the 16 taps sit in SGPRs.
+//    Every input row is read once per row-tile ((TH+3)/TH amplification, halo rows are L2/MALL hits
+//    thanks to the XCD-contiguous block order) and every output row is written once with dwordx4
+//    stores (non-temporal when the output cannot stay in the 256 MiB Infinity Cache).
+//    Edge lanes do NOT branch: a segment that straddles the row's ends is still one vector load
+//    (the bytes belong to the neighbouring row of the same tensor) and row-invariant masks zero the
+//    out-of-range columns.  (A per-element guarded path for those lanes cost 15 %: 527 -> 451 us.)
+//    fmgan_upfirdn2d_strided lets the producer hand over rows padded to a 128-byte multiple with the
+//    first tap column on a 16-byte boundary (op/_native.py::aligned_rows_buffer): 415 us = 5.18 TB/s.
+//  * Path 2 ("plane-tile") stages whole small planes (<= ~110x110) in LDS with one flat coalesced
+//    copy: at 4..64 px the planes are too narrow for a wave-wide strip.
+//  * Path 3 (up=2 polyphase, the ToRGB skip upsample): 2x4 outputs per thread, only the 2x2 taps
+//    that meet a non-zero sample of the zero-stuffed input are visited; store-bound.
 //  * Path 0 is the generic fallback (any up/down/pad/kernel/minor, f32/f64/f16).
 #include "common.h"
 
