@@ -68,15 +68,23 @@ __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict
   }
 }
 
-// ------------------------------------------------------------------ weight prep: wt[i][t][o] = scale*W[o][i][t]
+// ------------------------------------------------------------------ weight prep
+// kind 0 (forward):                          wt[i][t][o] = scale * W[o][i][t]
+// kind 1 (data-gradient of the plain conv):  wt[o][t][i] = scale * W[o][i][ktaps-1-t]   (taps flipped, roles swapped)
+// kind 2 (data-gradient of the transposed):  wt[o][t][i] = scale * W[o][i][t]           (roles swapped)
 __global__ __launch_bounds__(256) void modconv_weight_prep_f32(const float* __restrict__ W, float* __restrict__ wt,
-                                                               int cout, int cin, int ktaps, float scale) {
+                                                               int cout, int cin, int ktaps, float scale, int kind) {
   const long long total = (long long)cout * cin * ktaps;
+  const int cols = kind == 0 ? cout : cin;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int o = (int)(idx % cout);
-    const long long r = idx / cout;  // i*ktaps + t
-    wt[idx] = scale * W[(long long)o * cin * ktaps + r];
+    const int c = (int)(idx % cols);
+    const long long rt = idx / cols;
+    const int t = (int)(rt % ktaps), r = (int)(rt / ktaps);
+    float v;
+    if (kind == 0) v = W[((long long)c * cin + r) * ktaps + t];
+    else v = W[((long long)r * cin + c) * ktaps + (kind == 1 ? ktaps - 1 - t : t)];
+    wt[idx] = scale * v;
   }
 }
 
@@ -115,6 +123,8 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 }
 
 // MODE 0: plain 3x3, one output pixel per position, 9 taps.
+// MODE 2: stride-2 valid 3x3 (the reference's downsample branch, and the data-gradient of MODE 1):
+//         out[y,x] = sum w[ky][kx] * in[2y+ky, 2x+kx]; same contraction as MODE 0 over a stride-2 patch.
 // MODE 1: transposed stride-2 3x3. Position (m,n) owns the 2x2 output quad (2m+py, 2n+px); its four phases
 //         use 4+2+2+1 = 9 taps of the same staged weights and only 4 distinct input offsets:
 //         out[2m+py, 2n+px] += w[ky][kx] * in[m - ky/2, n - kx/2],  ky = py (mod 2), kx = px (mod 2).
@@ -138,7 +148,9 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   if (si > 0) lb -= p.seg[si - 1].block_end;
   const int seg_th = p.seg[si].th, seg_nb = p.seg[si].nb, tw_log2 = p.seg[si].tw_log2;
   const int seg_m_end = p.seg[si].m_off + p.seg[si].gh, seg_n_end = p.seg[si].n_off + p.seg[si].gw;
-  const int TW = 1 << tw_log2, PWP = TW + 2;
+  constexpr int SP = MODE == 2 ? 2 : 1;          // input step per position
+  constexpr int ORG = MODE == 2 ? 0 : 1;         // patch origin = SP * first position - ORG
+  const int TW = 1 << tw_log2, PWP = SP * (TW - 1) + 3;
   const int o_tile = lb % p.o_tiles;
   unsigned pt = lb / p.o_tiles;
   const int tx_i = pt % p.seg[si].tiles_x; pt /= p.seg[si].tiles_x;
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   const int ks = blockIdx.y;
   const int o0 = o_tile * BM, b0 = tb_i * seg_nb;
   const int x0 = p.seg[si].n_off + tx_i * TW, y0 = p.seg[si].m_off + ty_i * seg_th;   // first position of the tile
-  const int PH = seg_th + 2;
+  const int PH = SP * (seg_th - 1) + 3;
   const int plane = PH * PWP;
   const int samp = KC * plane;
 
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
     const int pos = (wn * RNP + g) * 32 + l31;
     const int tx = pos & (TW - 1), r = pos >> tw_log2;
     const int ty = r % seg_th, nbi = r / seg_th;
-    pbase[g] = nbi * samp + ty * PWP + tx;
+    pbase[g] = nbi * samp + SP * ty * PWP + SP * tx;
     pos_b[g] = b0 + nbi; pos_y[g] = y0 + ty; pos_x[g] = x0 + tx;
   }
 
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   // each; weights: NWV float4 per thread.  Everything a chunk needs is loaded into registers one chunk AHEAD
   // (while the previous chunk is on the matrix pipe) and written to LDS after the barrier.
   constexpr int BNP = 32 * RNP * WN;
-  constexpr int NU = ((BNP / 32 + 2) * 34 + 255) / 256;          // covers a full-width main tile
+  constexpr int NU = ((SP * (BNP / 32 - 1) + 3) * (SP * 31 + 3) + 255) / 256;   // covers a full-width main tile
   constexpr int NWV = (KC * 9 * (BM / 4) + 255) / 256;
   const int spatial = seg_nb * plane;                              // patch slots per channel
   // element offsets are 32-bit, relative to the tile's first sample (host checks nb*cin*h*w < 2^31)
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
     const int c = q % PWP;
     int t = q / PWP;
     const int r = t % PH, nbi = t / PH;
-    const int b = b0 + nbi, y = y0 + r - 1, x = x0 + c - 1;
+    const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG;
     inb[u] = q < spatial && b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
     gofs[u] = (nbi * p.cin * p.h + y) * p.w + x;
     sofs[u] = nbi * p.cin;
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
       const int c = q % PWP;
       int t = q / PWP;
       const int r = t % PH, nbi = t / PH;
-      const int b = b0 + nbi, y = y0 + r - 1, x = x0 + c - 1;
+      const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG;
       const bool ok = b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
       for (int kc = 0; kc < KC; ++kc) {
         const int i = i0 + kc;
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
     }
   };
   auto mma = [&](const Ops& o) {
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -353,10 +365,10 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
         const int b = pos_b[g];
         if (b >= p.batch) continue;
         float* dplane = dstbase + ((long long)b * p.cout + o) * dps;
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
           const int y = pos_y[g], x = pos_x[g];
-          if (y >= p.h || x >= p.w) continue;
-          const int pix = y * p.w + x;
+          if (y >= p.oh || x >= p.ow) continue;
+          const int pix = y * p.ow + x;
           float v = acc[m][g][0][r];
           if (!partial) v = mc_epilogue(v, p, nw, b, o, pix);
           dplane[(long long)y * drs + x] = v;
@@ -428,6 +440,7 @@ inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
 template <int MODE, int RM, int RNP, int WM, int WN>
 int launch_cfg(MCParams& p, hipStream_t s) {
   constexpr int BM = 32 * RM * WM, BN = 32 * RNP * WN;
+  constexpr int SP = MODE == 2 ? 2 : 1;
   p.o_tiles = (p.cout + BM - 1) / BM;
   long long blocks = 0;
   size_t patch = 0;
@@ -437,7 +450,7 @@ int launch_cfg(MCParams& p, hipStream_t s) {
     p.seg[i].block_end = (unsigned)blocks;
     // 32-bit in-tile element offsets: (nb samples) x cin x h x w must fit
     if ((long long)p.seg[i].nb * p.cin * p.h * p.w >= (1LL << 31)) return FMGAN_EOVERFLOW;
-    const size_t f = (size_t)p.seg[i].nb * MC_KC * (p.seg[i].th + 2) * ((1 << p.seg[i].tw_log2) + 2);
+    const size_t f = (size_t)p.seg[i].nb * MC_KC * (SP * (p.seg[i].th - 1) + 3) * (SP * ((1 << p.seg[i].tw_log2) - 1) + 3);
     if (f > patch) patch = f;
   }
   const size_t lds = sizeof(float) * ((size_t)MC_KC * 9 * BM + patch);
@@ -451,6 +464,7 @@ inline int pick_cfg(int mode, int cout, long long positions) {
     if (positions <= 2048) return 3;          // tiny layers: many small tiles (+ split-K)
     return cout >= 96 ? 0 : (cout >= 48 ? 1 : 2);
   }
+  if (mode == 2) return cout >= 96 ? 0 : (cout >= 48 ? 1 : 3);   // stride-2 patches are 4x larger: 128 positions only
   return cout >= 48 ? 1 : 2;
 }
 
@@ -458,6 +472,9 @@ inline void cfg_dims(int mode, int cfg, int& BM, int& BN) {
   if (mode == 0) {
     const int bm[4] = {128, 64, 32, 32}, bn[4] = {128, 256, 512, 128};
     BM = bm[cfg]; BN = bn[cfg];
+  } else if (mode == 2) {
+    const int bm[4] = {128, 64, 32, 32};
+    BM = bm[cfg]; BN = 128;
   } else {
     BM = cfg == 1 ? 64 : 32; BN = cfg == 1 ? 128 : 256;
   }
@@ -472,13 +489,27 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
       default: return launch_cfg<0, 1, 1, 1, 4>(p, s);
     }
   }
+  if (mode == 2) {
+    switch (cfg) {
+      case 0: return launch_cfg<2, 2, 2, 2, 2>(p, s);
+      case 1: return launch_cfg<2, 2, 1, 1, 4>(p, s);
+      default: return launch_cfg<2, 1, 1, 1, 4>(p, s);
+    }
+  }
   return cfg == 1 ? launch_cfg<1, 2, 1, 1, 4>(p, s) : launch_cfg<1, 1, 2, 1, 4>(p, s);
 }
 
 // Blocks of one launch (all segments), for a given tile configuration.
+inline void out_dims(int mode, int h, int w, int& oh, int& ow) {
+  if (mode == 1) { oh = 2 * h + 1; ow = 2 * w + 1; }
+  else if (mode == 2) { oh = (h - 3) / 2 + 1; ow = (w - 3) / 2 + 1; }
+  else { oh = h; ow = w; }
+}
+
 inline long long count_blocks(int mode, int cfg, int batch, int cout, int h, int w) {
   int BM, BN;
   cfg_dims(mode, cfg, BM, BN);
+  if (mode == 2) out_dims(2, h, w, h, w);   // positions = outputs
   MCParams::Seg sg[3] = {{0, 0, h, w}, {h, 0, 1, w + 1}, {0, w, h, 1}};   // any order: only the sum matters
   long long blocks = 0;
   for (int i = 0; i < (mode == 1 ? 3 : 1); ++i) blocks += plan_segment(sg[i], batch, BN);
@@ -490,7 +521,9 @@ inline long long count_blocks(int mode, int cfg, int batch, int cout, int h, int
 // (plus a fixed prologue/epilogue per block and a finish pass over ks partial slabs).  Pick the ks that minimises
 // the modelled time; layers with many rounds keep ks = 1.
 inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
-  const int cfg = pick_cfg(mode, cout, (long long)batch * h * w);
+  int poh, pow_;
+  out_dims(mode == 2 ? 2 : 0, h, w, poh, pow_);   // position grid (mode 1: the input grid)
+  const int cfg = pick_cfg(mode, cout, (long long)batch * poh * pow_);
   const long long blocks = count_blocks(mode, cfg, batch, cout, h, w);
   const int chunks = (cin + MC_KC - 1) / MC_KC;
   const int slots = FMGAN_NUM_CU * ((mode == 0 && cfg == 3) ? 4 : 2);   // co-resident blocks (VGPR-limited)
@@ -500,7 +533,9 @@ inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
   // time unit: one chunk of one block.  Finish pass: (2*ks + 1) * out_bytes at ~4 TB/s against ~5 us per full-size chunk
   const double mfma_per_chunk = (double)(BM / 32) * (BN / 32) * (mode == 1 ? 9 : 9) * (MC_KC / 2) / 4.0;  // per wave
   const double t_chunk_us = mfma_per_chunk * 64.0 / 2360.0 * 2.0;       // two blocks share each SIMD
-  const double out_mb = (double)batch * cout * (mode == 1 ? (2.0 * h + 1) * (2.0 * w + 1) : (double)h * w) * 4e-6;
+  int ooh, oow;
+  out_dims(mode, h, w, ooh, oow);
+  const double out_mb = (double)batch * cout * ooh * (double)oow * 4e-6;
   int best = 1;
   double best_t = 1e30;
   for (int ks = 1; ks <= 16 && ks <= chunks / 2; ++ks) {
@@ -582,22 +617,25 @@ extern "C" int fmgan_modconv_demod_f32(const float* weight, const float* style, 
 }
 
 extern "C" int fmgan_modconv_weight_prep_f32(const float* weight, float* wt, int cout, int cin, int ktaps, float scale,
-                                             void* stream) {
+                                             int kind, void* stream) {
   if (cout <= 0 || cin <= 0 || ktaps <= 0) return FMGAN_EINVAL;
+  if (kind < 0 || kind > 2) return FMGAN_EUNSUPPORTED;
   if (!weight || !wt) return FMGAN_EINVAL;
   const long long total = (long long)cout * cin * ktaps;
   long long blocks = (total + 255) / 256;
   if (blocks > FMGAN_NUM_CU * 16) blocks = FMGAN_NUM_CU * 16;
   hipLaunchKernelGGL(modconv_weight_prep_f32, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weight, wt,
-                     cout, cin, ktaps, scale);
+                     cout, cin, ktaps, scale, kind);
   return fmgan_check_launch();
 }
 
 extern "C" long long fmgan_modconv2d_workspace_bytes(int batch, int cin, int cout, int h, int w, int mode) {
-  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (mode != 0 && mode != 1)) return 0;
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || mode < 0 || mode > 2) return 0;
+  if (mode == 2 && (h < 3 || w < 3)) return 0;
   const int ks = pick_ksplit(mode, batch, cin, cout, h, w);
   if (ks <= 1) return 0;
-  const long long oh = mode == 1 ? 2 * h + 1 : h, ow = mode == 1 ? 2 * w + 1 : w;
+  int oh, ow;
+  out_dims(mode, h, w, oh, ow);
   return (long long)ks * batch * cout * oh * ow * (long long)sizeof(float);
 }
 
@@ -607,16 +645,16 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
                                    int fuse_act, float alpha, float act_scale, long long out_plane_stride,
                                    int out_row_stride, void* workspace, long long workspace_bytes, void* stream) {
   if (batch < 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return FMGAN_EINVAL;
-  if (mode != 0 && mode != 1) return FMGAN_EUNSUPPORTED;
-  if (mode == 1 && fuse_act) return FMGAN_EUNSUPPORTED;  // the blur sits between conv and activation
+  if (mode < 0 || mode > 2) return FMGAN_EUNSUPPORTED;
+  if (mode != 0 && fuse_act) return FMGAN_EUNSUPPORTED;  // the blur sits between conv and activation
+  if (mode == 2 && (h < 3 || w < 3)) return FMGAN_EINVAL;
   if (batch == 0) return FMGAN_OK;
   if (!in || !wt || !style || !out) return FMGAN_EINVAL;
   if (fuse_act && noise && noise_batch != 1 && noise_batch != batch) return FMGAN_EINVAL;
   MCParams p{};
   p.in = in; p.wt = wt; p.style = style; p.demod = demod; p.out = out;
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
-  p.oh = mode == 1 ? 2 * h + 1 : h;
-  p.ow = mode == 1 ? 2 * w + 1 : w;
+  out_dims(mode, h, w, p.oh, p.ow);
   if (out_row_stride == 0) out_row_stride = p.ow;
   if (out_plane_stride == 0) out_plane_stride = (long long)p.oh * out_row_stride;
   if (out_row_stride < p.ow || out_plane_stride < (long long)p.oh * out_row_stride) return FMGAN_EINVAL;
@@ -625,7 +663,7 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
   p.noise_batch = noise_batch; p.fuse_act = fuse_act; p.alpha = alpha; p.act_scale = act_scale;
   if ((long long)batch * cout * p.oh * p.ow > (1LL << 40)) return FMGAN_EOVERFLOW;
   hipStream_t s = (hipStream_t)stream;
-  const int cfg = pick_cfg(mode, cout, (long long)batch * h * w);
+  const int cfg = pick_cfg(mode, cout, (long long)batch * (mode == 2 ? p.oh * p.ow : h * w));
   // split-K only when the caller supplied the workspace fmgan_modconv2d_workspace_bytes() asks for
   p.ksplit = pick_ksplit(mode, batch, cin, cout, h, w);
   const long long need = (long long)p.ksplit * batch * cout * p.oh * p.ow * (long long)sizeof(float);
@@ -643,7 +681,7 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
     p.seg[2] = {0, 0, h, w};
     p.nseg = 3;
   } else {
-    p.seg[0] = {0, 0, h, w};
+    p.seg[0] = {0, 0, p.oh, p.ow};      // mode 0: oh = h; mode 2: the output grid
     p.nseg = 1;
   }
   int st = launch_any(mode, cfg, p, s);

@@ -44,7 +44,7 @@ def lib():
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
-    _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, vp])
+    _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, i, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
@@ -210,13 +210,16 @@ def modconv_demod(weight, style, scale, eps=1e-8):
     return demod
 
 
-def modconv_weight_prep(weight, scale):
-    """[.., cout,cin,k,k] -> wt [cin, k*k, cout] = scale * weight, the MFMA A-operand layout."""
+def modconv_weight_prep(weight, scale, kind=0):
+    """[.., cout,cin,k,k] -> MFMA A-operand layout of scale*weight: kind 0 [cin, k*k, cout] (forward);
+    kind 1 [cout, k*k, cin] with flipped taps (data-gradient of the plain conv); kind 2 [cout, k*k, cin]
+    (data-gradient of the transposed conv)."""
     cout, cin, kh, kw = weight.shape[-4:]
-    wt = torch.empty((cin, kh * kw, cout), dtype=torch.float32, device=weight.device)
+    shape = (cin, kh * kw, cout) if kind == 0 else (cout, kh * kw, cin)
+    wt = torch.empty(shape, dtype=torch.float32, device=weight.device)
     with on_device(weight) as stream:
-        check(lib().fmgan_modconv_weight_prep_f32(ptr(weight), ptr(wt), cout, cin, kh * kw, float(scale), stream),
-              'modconv_weight_prep')
+        check(lib().fmgan_modconv_weight_prep_f32(ptr(weight), ptr(wt), cout, cin, kh * kw, float(scale), int(kind),
+                                                  stream), 'modconv_weight_prep')
     return wt
 
 
@@ -241,7 +244,7 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
     style = style.contiguous()
     b, cin, h, w = x.shape
     cout = wt.shape[2]
-    oh, ow = (2 * h + 1, 2 * w + 1) if mode == 1 else (h, w)
+    oh, ow = (2 * h + 1, 2 * w + 1) if mode == 1 else (((h - 3) // 2 + 1, (w - 3) // 2 + 1) if mode == 2 else (h, w))
     if strided_out is None:
         out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=x.device)
         out_ptr, ops, ors = out.data_ptr(), 0, 0

@@ -45,21 +45,70 @@ def _regrad(fn, saved, need, grad_out):
 
 
 class ModulatedConv2dFunction(Function):
-    """3x3 modulated conv (mode 0) / transposed stride-2 conv (mode 1) on the MFMA kernel."""
+    """3x3 modulated conv on the MFMA kernel: mode 0 plain, 1 transposed stride 2, 2 stride-2 valid.
+
+    backward, first order (no graph requested): the data gradient runs on the SAME kernel with swapped roles —
+        d/dx of mode 0:  g_u = conv(go * d, W^T flipped)            -> mode 0 with weight layout kind 1
+        d/dx of mode 1:  g_u = stride-2 conv(go * d, W^T)           -> mode 2 with weight layout kind 2
+    where u = x * s is the modulated input and the factor d (demodulation) rides as the kernel's input modulation;
+    g_x = g_u * s.  The weight gradient is MIOpen's wgrad on (u, go*d) for now; the demodulation chain rule is
+    small [B,Cout]x[Cout,Cin] algebra.  When a graph is requested (R1 / path-length regularisers), the whole
+    backward is the differentiable composite instead.
+    """
 
     @staticmethod
     def forward(ctx, x, weight, s, wt, demodulate, mode, scale):
         demod = _native.modconv_demod(weight, s, scale) if demodulate else None
         out = _native.modconv2d(x, wt, s, demod, mode)
-        ctx.save_for_backward(x, weight, s)
+        saved = [x, weight, s] + ([demod, out] if demodulate else [])
+        ctx.save_for_backward(*saved)
         ctx.cfg = (demodulate, mode, scale)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         demodulate, mode, scale = ctx.cfg
-        gx, gw, gs = _regrad(lambda x, w, s: modconv_composite(x, w, s, demodulate, mode, scale),
-                             ctx.saved_tensors, ctx.needs_input_grad[:3], grad_out)
+        x, weight, s = ctx.saved_tensors[:3]
+        need = ctx.needs_input_grad[:3]
+        if torch.is_grad_enabled() or mode == 2 or grad_out.dtype != torch.float32:
+            gx, gw, gs = _regrad(lambda a, b, c: modconv_composite(a, b, c, demodulate, mode, scale), (x, weight, s),
+                                 need, grad_out)
+            return gx, gw, gs, None, None, None, None
+        go = grad_out.contiguous()
+        cout, cin, k, _ = weight.shape[-4:]
+        w4 = weight.reshape(cout, cin, k, k)
+        batch = x.shape[0]
+        d = ctx.saved_tensors[3] if demodulate else None
+        dstyle = d if demodulate else torch.ones(batch, cout, dtype=torch.float32, device=x.device)
+        gx = gw = gs = None
+        gu = None
+        if need[0] or need[2]:
+            # data gradient on the MFMA kernel (roles of Cin / Cout swapped)
+            wt_b = _native.modconv_weight_prep(w4, scale, kind=1 if mode == 0 else 2)
+            gu = _native.modconv2d(go, wt_b, dstyle, None, 0 if mode == 0 else 2)
+            if need[0]:
+                gx = gu * s[:, :, None, None]
+            if need[2]:
+                gs = (gu * x).sum((2, 3))
+        gq = None
+        if demodulate and (need[1] or need[2]):
+            out = ctx.saved_tensors[4]
+            # d = q^-1/2 with q = scale^2 sum_i s^2 Wsq + eps;  dL/dq = dL/dd * (-1/2) d^3,  dL/dd = sum_p go*out / d
+            gq = -0.5 * (go * out).sum((2, 3)) * d * d
+            wsq = w4.square().sum((2, 3))                                  # [cout, cin]
+            if need[2]:
+                gs = gs + (2.0 * scale * scale) * s * (gq @ wsq)
+        if need[1]:
+            gz = go * d[:, :, None, None] if demodulate else go
+            u = x * s[:, :, None, None]
+            if mode == 0:
+                gw = torch.nn.grad.conv2d_weight(u, (cout, cin, k, k), gz, padding=k // 2)
+            else:   # y = conv_transpose2d(u, W^T, stride 2) is the adjoint of conv2d(., W^T, stride 2)
+                gw = torch.nn.grad.conv2d_weight(gz, (cin, cout, k, k), u, stride=2).transpose(0, 1)
+            gw = gw * scale
+            if gq is not None:
+                gw = gw + (2.0 * scale * scale) * w4 * (gq.t() @ s.square())[:, :, None, None]
+            gw = gw.reshape(weight.shape)
         return gx, gw, gs, None, None, None, None
 
 
@@ -102,7 +151,7 @@ def modulated_conv2d(x, weight, s, wt, demodulate, mode, scale):
     """Dispatch: f32 3x3 -> MFMA kernel; anything else the reference allows (other kernel sizes, f64 for
     gradcheck, the unused downsample branch) -> the PyTorch-ROCm composite.  Both run on the GPU."""
     _native.require_gpu(x, 'input')
-    if mode in (0, 1) and hip_conv_ok(x, weight):
+    if mode in (0, 1, 2) and hip_conv_ok(x, weight) and wt is not None:
         return ModulatedConv2dFunction.apply(x, weight, s, wt, demodulate, mode, scale)
     return modconv_composite(x, weight, s, demodulate, mode, scale)
 

@@ -194,11 +194,11 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input, style, return_style_scalars=False):
         s = self.styles(style)
         hip = modconv.hip_conv_ok(input, self.weight)
-        wt = self.mfma_weight() if hip and not self.downsample else None
+        wt = self.mfma_weight() if hip else None
         if self.upsample:
             out = self.blur(modconv.modulated_conv2d(input, self.weight, s, wt, self.demodulate, 1, self.scale))
         elif self.downsample:
-            out = modconv.modulated_conv2d(self.blur(input), self.weight, s, None, self.demodulate, 2, self.scale)
+            out = modconv.modulated_conv2d(self.blur(input), self.weight, s, wt, self.demodulate, 2, self.scale)
         else:
             out = modconv.modulated_conv2d(input, self.weight, s, wt, self.demodulate, 0, self.scale)
         if return_style_scalars:

@@ -132,13 +132,15 @@ int fmgan_modconv_demod_f32(const float *weight, const float *style, float *demo
                             float scale, float eps, void *stream);
 
 /*
- * Weight layout for the MFMA contraction: wt[i][tap][o] = scale * weight[o][i][tap]
- * (o contiguous, so a 32-lane MFMA A-operand read is one LDS bank row and staging is coalesced).
- *   weight [cout, cin, ktaps] f32, wt [cin, ktaps, cout] f32 pre-allocated.
+ * Weight layouts for the MFMA contraction (last index contiguous, so a 32-lane MFMA A-operand read is one LDS bank
+ * row and staging is coalesced).  weight [cout, cin, ktaps] f32; wt pre-allocated, cout*cin*ktaps floats:
+ *   kind 0  wt[i][tap][o] = scale * weight[o][i][tap]            forward (modes 0, 1, and the downsample branch, mode 2)
+ *   kind 1  wt[o][tap][i] = scale * weight[o][i][ktaps-1-tap]    data-gradient of the plain conv    (run as mode 0)
+ *   kind 2  wt[o][tap][i] = scale * weight[o][i][tap]            data-gradient of the transposed conv (run as mode 2)
  * Depends on the parameter only — the host shim caches it per parameter version.
  */
 int fmgan_modconv_weight_prep_f32(const float *weight, float *wt, int cout, int cin, int ktaps,
-                                  float scale, void *stream);
+                                  float scale, int kind, void *stream);
 
 /*
  * Modulated 3x3 convolution, input-modulated form with batch-shared weights
@@ -148,6 +150,9 @@ int fmgan_modconv_weight_prep_f32(const float *weight, float *wt, int cout, int 
  *             wt[i,ky*3+kx,o] * style[b,i] * in[b,i,y+ky-1,x+kx-1]                 out [b,o,h,w]
  *   mode 1 (transposed, stride 2, pad 0; stylegan2.py:268-277):                    out [b,o,2h+1,2w+1]
  *             out[b,o,Y,X] = demod[b,o] * sum_{i, 2y+ky=Y, 2x+kx=X} wt[i,ky*3+kx,o]*style[b,i]*in[b,i,y,x]
+ *   mode 2 (stride 2, pad 0; the downsample branch stylegan2.py:281-286 after its blur, and the data-gradient of
+ *             mode 1):  out[b,o,y,x] = demod[b,o] * sum_{i,ky,kx} wt[i,ky*3+kx,o]*style[b,i]*in[b,i,2y+ky,2x+kx]
+ *                                                                                    out [b,o,(h-3)/2+1,(w-3)/2+1]
  *   in [batch,cin,h,w], wt from fmgan_modconv_weight_prep_f32 (ktaps = 9), style [batch,cin],
  *   demod [batch,cout] or NULL (no demodulation); out pre-allocated; all f32 contiguous.
  * Optional fused StyledConv epilogue (mode 0 only; stylegan2.py:371-373), enabled by fuse_act != 0:

@@ -50,6 +50,9 @@ def test_modulated_conv_golden(c, golden):
     (2, 33, 32, 16, 16, 0), (2, 33, 32, 16, 16, 1), (1, 16, 100, 33, 35, 0), (1, 16, 100, 33, 35, 1),
     (2, 8, 50, 70, 40, 0), (2, 8, 50, 70, 40, 1), (1, 40, 20, 64, 64, 0), (1, 40, 20, 64, 64, 1),
     (9, 5, 3, 5, 3, 0), (9, 5, 3, 5, 3, 1),
+    # mode 2: stride-2 valid conv (downsample branch; data-gradient of mode 1)
+    (5, 12, 130, 9, 9, 2), (3, 7, 64, 17, 17, 2), (2, 33, 32, 33, 33, 2), (1, 16, 100, 67, 71, 2),
+    (2, 8, 50, 141, 81, 2), (1, 40, 20, 129, 129, 2), (9, 5, 3, 11, 7, 2), (4, 130, 12, 9, 9, 2),
 ])
 @pytest.mark.parametrize('demod', [True, False])
 def test_modconv_kernel_vs_c_oracle(cfg, demod):
@@ -118,6 +121,67 @@ def test_torgb_kernel_vs_c_oracle_ragged():
         ref = c_oracle.to_rgb(x.numpy(), wgt.numpy(), s.numpy(), bias.numpy(), skip.numpy())
         y = _native.torgb(x.to(dev()), wgt.to(dev()), s.to(dev()), bias.to(dev()), skip.to(dev()), 1.0 / np.sqrt(cin))
         np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+
+
+def test_weight_prep_layouts():
+    from op import _native
+    w = synth.tensor('wprep/w', (20, 12, 3, 3))
+    wd = w.to(dev())
+    k0 = _native.modconv_weight_prep(wd, 0.5, 0).cpu().numpy()
+    k1 = _native.modconv_weight_prep(wd, 0.5, 1).cpu().numpy()
+    k2 = _native.modconv_weight_prep(wd, 0.5, 2).cpu().numpy()
+    wn = (w.numpy() * np.float32(0.5)).reshape(20, 12, 9)
+    np.testing.assert_array_equal(k0, wn.transpose(1, 2, 0))
+    np.testing.assert_array_equal(k1, wn[:, :, ::-1].transpose(0, 2, 1))
+    np.testing.assert_array_equal(k2, wn.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize('cfg', [(2, 6, 10, 5, False, True), (2, 6, 10, 5, True, True), (3, 20, 136, 8, False, True),
+                                 (3, 20, 136, 8, True, True), (1, 9, 70, 20, True, False), (2, 16, 8, 16, False, False)])
+def test_first_order_backward_on_hip_vs_oracle(cfg):
+    """loss.backward() without create_graph: data gradient on the MFMA kernel (swapped-role weight layouts, stride-2
+    mode for the transposed conv), weight gradient + demodulation chain rule; vs float64 autograd through the CPU
+    oracle's weight-modulated grouped conv (the reference's formulation)."""
+    import stylegan2
+    from oracle import torch_oracle as T
+    b, cin, cout, h, up, demod = cfg
+    m = stylegan2.ModulatedConv2d(cin, cout, 3, 512, demodulate=demod, upsample=up)
+    m.load_state_dict(synth.state_dict('generator', m.state_dict(), seed=21))
+    sd = {k: v.detach().double() for k, v in m.state_dict().items()}
+    m = m.to(dev())
+    x = synth.tensor(f'bw/{cfg}/x', (b, cin, h, h))
+    w = synth.tensor(f'bw/{cfg}/w', (b, 512))
+    xo, wo = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    wt_o, mw_o, mb_o = (sd[k].clone().requires_grad_(True) for k in ('weight', 'modulation.weight', 'modulation.bias'))
+    yo = T.modulated_conv2d(xo, wo, wt_o, mw_o, mb_o, demod, up, [1, 3, 3, 1])
+    go = synth.tensor(f'bw/{cfg}/go', yo.shape)
+    ref = torch.autograd.grad(yo, (xo, wo, wt_o, mw_o, mb_o), go.double())
+    xd, wd = x.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    yd = m(xd, wd)
+    yd.backward(go.to(dev()))                     # no graph requested -> HIP first-order path
+    got = (xd.grad, wd.grad, m.weight.grad, m.modulation.weight.grad, m.modulation.bias.grad)
+    for name, g, r in zip(('x', 'latent', 'weight', 'mod.weight', 'mod.bias'), got, ref):
+        r = r.numpy()
+        np.testing.assert_allclose(g.cpu().numpy(), r, atol=2e-4 * max(1e-6, float(np.abs(r).max())), rtol=2e-4,
+                                   err_msg=name)
+
+
+def test_downsample_branch_on_hip_vs_composite():
+    """ModulatedConv2d(downsample=True) (stylegan2.py:281-286; unused by the Generator, kept for API parity): blur then
+    the stride-2 MFMA mode vs the PyTorch-ROCm composite."""
+    import stylegan2
+    from op import modconv
+    m = stylegan2.ModulatedConv2d(12, 20, 3, 512, downsample=True)
+    m.load_state_dict(synth.state_dict('generator', m.state_dict(), seed=22))
+    m = m.to(dev())
+    x = synth.tensor('ds/x', (2, 12, 16, 16)).to(dev())
+    w = synth.tensor('ds/w', (2, 512)).to(dev())
+    with torch.no_grad():
+        y = m(x, w)
+        s = m.modulation(w)
+        ref = modconv.modconv_composite(m.blur(x), m.weight, s, True, 2, m.scale)
+    assert tuple(y.shape) == (2, 20, 8, 8)
+    torch.testing.assert_close(y, ref, atol=2e-5 * float(ref.abs().max()), rtol=1e-5)
 
 
 def test_modconv_gradients_match_reference_formulation():
