@@ -547,6 +547,144 @@ inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
   return best;
 }
 
+// ------------------------------------------------------------------ weight gradient of the plain conv (MFMA)
+// gw[o,i,ky,kx] = sum_{b,y,x} (d[b,o] * go[b,o,y,x]) * (s[b,i] * x[b,i,y+ky-1,x+kx-1])
+// GEMM with M = Cout (A rows), N = Cin (B columns), K = pixels; the 9 taps are 9 accumulators that share the A
+// operand and read B at 9 constant offsets of the staged halo patch.  A block owns a 32(o) x 32(i) tile; its four
+// waves take the four 32-pixel quarters of each 128-pixel tile (so a chunk is 16 K-steps x 9 MFMAs per wave) and are
+// summed through LDS at the end; the pixel range is split over blocks (fixed-order finish, no atomics).
+struct WGParams {
+  const float* go; const float* d; const float* x; const float* s; float* partial;
+  int batch, cin, cout, h, w;
+  int tw_log2, th, tiles_x, tiles_y, ntiles, ksplit, tiles_per_split, o_tiles, i_tiles;
+};
+
+__global__ __launch_bounds__(256, 2) void modconv_wgrad_f32(const WGParams p) {
+  constexpr int SA = 129;                      // Gz row stride (128 pixels + 1: conflict-free across o)
+  extern __shared__ float smem[];
+  const int TW = 1 << p.tw_log2, PWP = TW + 2, PH = p.th + 2;
+  const int SB = PH * PWP + 1 + ((PH * PWP) & 1);   // odd stride: conflict-free across i
+  float* Gz = smem;                            // [32][SA]
+  float* Us = smem + 32 * SA;                  // [32][SB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tile = lb % p.o_tiles;
+  const int i_tile = (lb / p.o_tiles) % p.i_tiles;
+  const int ks = lb / (p.o_tiles * p.i_tiles);
+  const int o0 = o_tile * 32, i0 = i_tile * 32;
+  const int hw = p.h * p.w;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int t_begin = ks * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % p.tiles_x;
+    const int ty = (tile / p.tiles_x) % p.tiles_y;
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * p.th, x0 = tx * TW;
+    __syncthreads();
+    // A: 32 output channels x 128 pixels of d*go
+    for (int idx = tid; idx < 32 * 128; idx += 256) {
+      const int o = idx >> 7, pix = idx & 127;
+      const int y = y0 + (pix >> p.tw_log2), x = x0 + (pix & (TW - 1));
+      float v = 0.f;
+      if (o0 + o < p.cout && y < p.h && x < p.w) {
+        const long long ch = (long long)b * p.cout + o0 + o;
+        v = p.go[ch * hw + y * p.w + x];
+        if (p.d) v *= p.d[ch];
+      }
+      Gz[o * SA + pix] = v;
+    }
+    // B: 32 input channels x halo patch of s*x
+    const int patch = PH * PWP;
+    for (int idx = tid; idx < 32 * patch; idx += 256) {
+      const int i = idx / patch, q = idx - i * patch;
+      const int y = y0 + q / PWP - 1, x = x0 + q % PWP - 1;
+      float v = 0.f;
+      if (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w) {
+        const long long ch = (long long)b * p.cin + i0 + i;
+        v = p.x[ch * hw + y * p.w + x] * p.s[ch];
+      }
+      Us[i * SB + q] = v;
+    }
+    __syncthreads();
+    const float* ga = Gz + l31 * SA + wave * 32 + khalf;
+    const float* ub = Us + l31 * SB;
+    float a_cur, b_cur[9], a_nxt = 0.f, b_nxt[9];
+    auto fetch = [&](float& a, float (&bb)[9], int j) {
+      const int pix = wave * 32 + 2 * j + khalf;
+      const int off = (pix >> p.tw_log2) * PWP + (pix & (TW - 1));
+      a = ga[2 * j];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bb[t] = ub[off + (t / 3) * PWP + (t % 3)];
+    };
+    fetch(a_cur, b_cur, 0);
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 1 < 16) fetch(a_nxt, b_nxt, j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
+    }
+  }
+  // sum the four waves through LDS, one tap at a time, and write the block's partial slab [ks][t][o][i]
+  float* red = smem;   // [4][32][33]
+  float* slab = p.partial + (long long)ks * 9 * p.cout * p.cin;
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      red[(wave * 32 + o) * 33 + l31] = acc[t][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int o = e >> 5, i = e & 31;
+      const float v = red[o * 33 + i] + red[(32 + o) * 33 + i] + red[(64 + o) * 33 + i] + red[(96 + o) * 33 + i];
+      if (o0 + o < p.cout && i0 + i < p.cin) slab[((long long)t * p.cout + o0 + o) * p.cin + i0 + i] = v;
+    }
+  }
+}
+
+// gw[o][i][t] = scale * sum_ks partial[ks][t][o][i]
+__global__ __launch_bounds__(256) void modconv_wgrad_finish_f32(const float* __restrict__ partial, float* __restrict__ gw,
+                                                                int cout, int cin, int ksplit, float scale) {
+  const int total = cout * cin * 9;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int t = idx % 9, oi = idx / 9;
+    float v = 0.f;
+    for (int ks = 0; ks < ksplit; ++ks) v += partial[((long long)ks * 9 + t) * cout * cin + oi];
+    gw[idx] = v * scale;
+  }
+}
+
+inline void wgrad_plan(WGParams& p) {
+  p.tw_log2 = p.w >= 32 ? 5 : 4;
+  const int TW = 1 << p.tw_log2;
+  p.th = 128 / TW;
+  p.tiles_x = (p.w + TW - 1) / TW;
+  p.tiles_y = (p.h + p.th - 1) / p.th;
+  p.ntiles = p.batch * p.tiles_x * p.tiles_y;
+  p.o_tiles = (p.cout + 31) / 32;
+  p.i_tiles = (p.cin + 31) / 32;
+  const int pairs = p.o_tiles * p.i_tiles;
+  int ks = (FMGAN_NUM_CU * 6 + pairs - 1) / pairs;     // ~3 rounds of 2 blocks per CU
+  if (ks > p.ntiles) ks = p.ntiles;
+  if (ks < 1) ks = 1;
+  p.tiles_per_split = (p.ntiles + ks - 1) / ks;
+  p.ksplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+}
+
 // ------------------------------------------------------------------ ToRGB (1x1, <= 4 output channels, HBM-bound)
 template <int VEC>
 __global__ __launch_bounds__(256) void torgb_f32(const float* __restrict__ in, const float* __restrict__ weight,
@@ -694,6 +832,44 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
     st = fmgan_check_launch();
   }
   return st;
+}
+
+extern "C" long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w < 16) return 0;
+  WGParams p{};
+  p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
+  wgrad_plan(p);
+  return (long long)p.ksplit * 9 * cout * cin * (long long)sizeof(float);
+}
+
+extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, const float* x, const float* style,
+                                       float* gw, int batch, int cin, int cout, int h, int w, float scale,
+                                       void* workspace, long long workspace_bytes, void* stream) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return FMGAN_EINVAL;
+  if (w < 16) return FMGAN_EUNSUPPORTED;           // tiny layers: negligible FLOPs, the host keeps MIOpen's wgrad
+  if (!go || !x || !style || !gw || !workspace) return FMGAN_EINVAL;
+  if ((long long)batch * (cin > cout ? cin : cout) * h * w >= (1LL << 40)) return FMGAN_EOVERFLOW;
+  WGParams p{};
+  p.go = go; p.d = demod; p.x = x; p.s = style; p.partial = (float*)workspace;
+  p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
+  wgrad_plan(p);
+  if (workspace_bytes < (long long)p.ksplit * 9 * cout * cin * (long long)sizeof(float)) return FMGAN_EINVAL;
+  const int TW = 1 << p.tw_log2;
+  const int patch = (p.th + 2) * (TW + 2);
+  const int SB = patch + 1 + (patch & 1);
+  size_t lds = sizeof(float) * (32 * 129 + 32 * (size_t)SB);
+  if (lds < sizeof(float) * 4 * 32 * 33) lds = sizeof(float) * 4 * 32 * 33;
+  const long long blocks = (long long)p.o_tiles * p.i_tiles * p.ksplit;
+  if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(modconv_wgrad_f32, dim3((unsigned)blocks), dim3(256), lds, s, p);
+  int st = fmgan_check_launch();
+  if (st != FMGAN_OK) return st;
+  int fb = (cout * cin * 9 + 255) / 256;
+  if (fb > FMGAN_NUM_CU * 16) fb = FMGAN_NUM_CU * 16;
+  hipLaunchKernelGGL(modconv_wgrad_finish_f32, dim3(fb), dim3(256), 0, s, (const float*)workspace, gw, cout, cin,
+                     p.ksplit, scale);
+  return fmgan_check_launch();
 }
 
 extern "C" int fmgan_torgb_f32(const float* in, const float* weight, const float* style, const float* bias,

@@ -47,6 +47,8 @@ def lib():
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, i, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
+    _sig(L.fmgan_modconv_wgrad_workspace_bytes, [i] * 5, ll)
+    _sig(L.fmgan_modconv_wgrad_f32, [vp] * 5 + [i] * 5 + [f, vp, ll, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
     if L.fmgan_abi_version() != 1:
         raise RuntimeError('libfmgan_hip.so ABI version mismatch')
@@ -262,6 +264,25 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
                                         stream), 'modconv2d')
         _observer.end(tok)
     return out
+
+
+def modconv_wgrad(go, demod, x, style, scale):
+    """Conv part of the weight gradient of the plain modulated conv -> [cout,cin,3,3]; None if the shape is not
+    served by the kernel (w < 16)."""
+    go, x, style = go.contiguous(), x.contiguous(), style.contiguous()
+    b, cout, h, w = go.shape
+    cin = x.shape[1]
+    ws_bytes = lib().fmgan_modconv_wgrad_workspace_bytes(b, cin, cout, h, w)
+    if ws_bytes == 0:
+        return None
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    with on_device(x) as stream:
+        tok = _observer.begin('modconv_wgrad', (b, cin, cout, h, w))
+        check(lib().fmgan_modconv_wgrad_f32(ptr(go), ptr(demod), ptr(x), ptr(style), ptr(gw), b, cin, cout, h, w,
+                                            float(scale), ptr(ws), ws_bytes, stream), 'modconv_wgrad')
+        _observer.end(tok)
+    return gw
 
 
 def torgb(x, weight, style, bias, skip, scale):

@@ -5,13 +5,21 @@ regularisation differentiates through Generator.forward with create_graph=True, 
 autograd over F.conv2d / F.conv_transpose2d.  Here the backward re-states the same op as a differentiable
 composite of PyTorch-ROCm ops *in the input-modulated form* (dense convs with batch-shared weights, no
 [B*Cout,Cin,3,3] weight materialisation) and lets autograd differentiate that, so any derivative order works.
-HIP backward kernels are the next step for this row.
+Without a requested graph (plain loss.backward()) the data gradient runs on the MFMA kernel itself
+(ModulatedConv2dFunction.backward): 3 convolutions per layer per training step instead of the 4 of
+"HIP forward + recomputed composite".
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.nn import functional as F
 
 from . import _native
+
+# Weight gradient of the plain conv: MIOpen's fp32 wgrad measures 105-112 TFLOP/s on MI355X, this repo's
+# fmgan_modconv_wgrad_f32 50 TFLOP/s (synchronous staging; bit-reproducible) — MIOpen is the default.
+HIP_WGRAD = os.environ.get('FMGAN_HIP_WGRAD', '0') == '1'
 
 
 def modconv_composite(x, weight, s, demodulate, mode, scale, eps=1e-8):
@@ -51,8 +59,9 @@ class ModulatedConv2dFunction(Function):
         d/dx of mode 0:  g_u = conv(go * d, W^T flipped)            -> mode 0 with weight layout kind 1
         d/dx of mode 1:  g_u = stride-2 conv(go * d, W^T)           -> mode 2 with weight layout kind 2
     where u = x * s is the modulated input and the factor d (demodulation) rides as the kernel's input modulation;
-    g_x = g_u * s.  The weight gradient is MIOpen's wgrad on (u, go*d) for now; the demodulation chain rule is
-    small [B,Cout]x[Cout,Cin] algebra.  When a graph is requested (R1 / path-length regularisers), the whole
+    g_x = g_u * s.  The weight gradient is MIOpen's wgrad on (u, go*d) (an MFMA kernel of this repo exists,
+    fmgan_modconv_wgrad_f32, but is half as fast — see HIP_WGRAD).  The demodulation chain rule is small
+    [B,Cout]x[Cout,Cin] algebra.  When a graph is requested (R1 / path-length regularisers), the whole
     backward is the differentiable composite instead.
     """
 
@@ -99,13 +108,15 @@ class ModulatedConv2dFunction(Function):
             if need[2]:
                 gs = gs + (2.0 * scale * scale) * s * (gq @ wsq)
         if need[1]:
-            gz = go * d[:, :, None, None] if demodulate else go
-            u = x * s[:, :, None, None]
-            if mode == 0:
-                gw = torch.nn.grad.conv2d_weight(u, (cout, cin, k, k), gz, padding=k // 2)
-            else:   # y = conv_transpose2d(u, W^T, stride 2) is the adjoint of conv2d(., W^T, stride 2)
-                gw = torch.nn.grad.conv2d_weight(gz, (cin, cout, k, k), u, stride=2).transpose(0, 1)
-            gw = gw * scale
+            gw = _native.modconv_wgrad(go, d, x, s, scale) if (mode == 0 and HIP_WGRAD) else None
+            if gw is None:
+                gz = go * d[:, :, None, None] if demodulate else go
+                u = x * s[:, :, None, None]
+                if mode == 0:
+                    gw = torch.nn.grad.conv2d_weight(u, (cout, cin, k, k), gz, padding=k // 2)
+                else:   # y = conv_transpose2d(u, W^T, stride 2) is the adjoint of conv2d(., W^T, stride 2)
+                    gw = torch.nn.grad.conv2d_weight(gz, (cin, cout, k, k), u, stride=2).transpose(0, 1)
+                gw = gw * scale
             if gq is not None:
                 gw = gw + (2.0 * scale * scale) * w4 * (gq.t() @ s.square())[:, :, None, None]
             gw = gw.reshape(weight.shape)

@@ -177,6 +177,19 @@ int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
                         void *workspace, long long workspace_bytes, void *stream);
 
 /*
+ * Weight gradient of the plain (mode 0) modulated conv on the MFMA units:
+ *   gw[o,i,ky,kx] = scale * sum_{b,y,x} (demod[b,o] * go[b,o,y,x]) * (style[b,i] * x[b,i,y+ky-1,x+kx-1])
+ * (the conv part of d loss / d weight; the demodulation chain-rule term is [B,Cout]x[Cout,Cin] algebra on the host).
+ *   go [batch,cout,h,w], demod [batch,cout] or NULL, x [batch,cin,h,w], style [batch,cin], gw [cout,cin,3,3].
+ *   workspace: fmgan_modconv_wgrad_workspace_bytes() bytes (partial slabs of the split over pixels; fixed-order
+ *   finish, bit-reproducible).  w < 16 returns FMGAN_EUNSUPPORTED (0 workspace bytes): tiny layers stay on MIOpen.
+ */
+long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w);
+int fmgan_modconv_wgrad_f32(const float *go, const float *demod, const float *x, const float *style,
+                            float *gw, int batch, int cin, int cout, int h, int w, float scale,
+                            void *workspace, long long workspace_bytes, void *stream);
+
+/*
  * ToRGB (stylegan2.py:389-404): 1x1 modulated conv without demodulation + bias + optional skip:
  *   out[b,c,p] = sum_i scale*weight[c,i]*style[b,i]*in[b,i,p] + bias[c] (+ skip[b,c,p])
  *   in [batch,cin,hw], weight [cout,cin], style [batch,cin], bias [cout] or NULL,

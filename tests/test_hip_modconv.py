@@ -137,14 +137,17 @@ def test_weight_prep_layouts():
 
 
 @pytest.mark.parametrize('cfg', [(2, 6, 10, 5, False, True), (2, 6, 10, 5, True, True), (3, 20, 136, 8, False, True),
-                                 (3, 20, 136, 8, True, True), (1, 9, 70, 20, True, False), (2, 16, 8, 16, False, False)])
+                                 (3, 20, 136, 8, True, True), (1, 9, 70, 20, True, False), (2, 16, 8, 16, False, False),
+                                 (2, 40, 70, 32, False, True), (1, 33, 65, 40, False, True), (3, 8, 8, 24, False, True)])
 def test_first_order_backward_on_hip_vs_oracle(cfg):
     """loss.backward() without create_graph: data gradient on the MFMA kernel (swapped-role weight layouts, stride-2
     mode for the transposed conv), weight gradient + demodulation chain rule; vs float64 autograd through the CPU
     oracle's weight-modulated grouped conv (the reference's formulation)."""
     import stylegan2
     from oracle import torch_oracle as T
+    from op import modconv as _mc
     b, cin, cout, h, up, demod = cfg
+    _mc.HIP_WGRAD = (h % 8 == 0)        # exercise both weight-gradient providers (MFMA kernel / MIOpen)
     m = stylegan2.ModulatedConv2d(cin, cout, 3, 512, demodulate=demod, upsample=up)
     m.load_state_dict(synth.state_dict('generator', m.state_dict(), seed=21))
     sd = {k: v.detach().double() for k, v in m.state_dict().items()}
@@ -160,10 +163,28 @@ def test_first_order_backward_on_hip_vs_oracle(cfg):
     yd = m(xd, wd)
     yd.backward(go.to(dev()))                     # no graph requested -> HIP first-order path
     got = (xd.grad, wd.grad, m.weight.grad, m.modulation.weight.grad, m.modulation.bias.grad)
+    _mc.HIP_WGRAD = False
     for name, g, r in zip(('x', 'latent', 'weight', 'mod.weight', 'mod.bias'), got, ref):
         r = r.numpy()
         np.testing.assert_allclose(g.cpu().numpy(), r, atol=2e-4 * max(1e-6, float(np.abs(r).max())), rtol=2e-4,
                                    err_msg=name)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96, 64, 64), (1, 32, 32, 128, 128), (3, 100, 50, 17, 33), (8, 512, 512, 16, 16)])
+def test_wgrad_kernel_vs_fp64(shape):
+    """fmgan_modconv_wgrad_f32 vs a float64 conv weight gradient of the same (d*go, s*x) on the GPU."""
+    from op import _native
+    b, cin, cout, h, w = shape
+    go = synth.tensor(f'wg/{shape}/go', (b, cout, h, w)).to(dev())
+    x = synth.tensor(f'wg/{shape}/x', (b, cin, h, w)).to(dev())
+    s = synth.tensor(f'wg/{shape}/s', (b, cin), shift=1.0, scale=0.5).to(dev())
+    d = synth.tensor(f'wg/{shape}/d', (b, cout), shift=1.0, scale=0.3).to(dev())
+    gw = _native.modconv_wgrad(go, d, x, s, 0.37)
+    ref = torch.nn.grad.conv2d_weight((x * s[:, :, None, None]).double(), (cout, cin, 3, 3),
+                                      (go * d[:, :, None, None]).double(), padding=1) * 0.37
+    torch.testing.assert_close(gw.double(), ref, atol=2e-5 * float(ref.abs().max()), rtol=2e-5)
+    gw2 = _native.modconv_wgrad(go, d, x, s, 0.37)
+    assert torch.equal(gw, gw2)          # fixed-order split over pixels: bit-reproducible
 
 
 def test_downsample_branch_on_hip_vs_composite():
