@@ -146,13 +146,16 @@ class Replica(nn.Module):
         return self.module(*args, **kwargs)
 
 
-def data_parallel(module, device=None, overlap=True):
+def data_parallel(module, device=None, overlap=True, find_unused_parameters=True):
     """DataParallel replacement: DDP (bucketed RCCL all-reduce overlapped with backward) when a process group is up
-    and the module has trainable parameters, else a plain Replica."""
+    and the module has trainable parameters, else a plain Replica.  find_unused_parameters defaults to True because
+    the 3-encoder scheme leaves the Generator's mapping network and constant input unused (input_is_latent=True,
+    use_external_input_tensor=True; Util/network_util.py:329-330) — DDP would otherwise stall on their buckets."""
     if device is not None:
         module = module.to(device)
     if _active() and get_world_size() > 1 and overlap and any(p.requires_grad for p in module.parameters()):
         ids = [device.index] if (device is not None and device.type == 'cuda') else None
         return nn.parallel.DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=256,
-                                                   gradient_as_bucket_view=True)
+                                                   gradient_as_bucket_view=True,
+                                                   find_unused_parameters=find_unused_parameters)
     return Replica(module)

@@ -35,6 +35,10 @@ WORKLOADS = {
                       'Generator(1024) forward, fp32, B=8/GPU'),
     'pairs256': dict(size=256, batch=32, desc='E_Tsr+E_W+E_W_Plus(14 styles) on 256^2 -> co-mod -> Generator(256) '
                      'forward, fp32, B=32/GPU'),
+    # BASELINE config 3: forward + backward through the three encoders and the Generator (loss = L1 to a random target),
+    # eval-mode BatchNorm; with N > 1 the gradients are all-reduced by DDP over RCCL.
+    'train256': dict(size=256, batch=16, desc='cfg3: full 3-encoder forward+backward @256^2, fp32, B=16/GPU, '
+                     'grad all-reduce (DDP/RCCL) when N>1'),
 }
 
 
@@ -98,6 +102,28 @@ def make_step(nets, batch, device, rank):
         return forward(photo, render)
 
     step.forward = forward
+    return step, (photo, render)
+
+
+def make_train_step(nets, batch, device, rank, world):
+    """forward + backward of the (photo, render) -> image path; gradients w.r.t. every encoder and generator weight."""
+    from Miscellaneous import distributed as D
+    from Util.network_util import Forward_Inference_3_Encoder
+    for m in nets.values():
+        m.requires_grad_(True)
+    wrapped = {k: D.data_parallel(m, device) for k, m in nets.items()}
+    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+    render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+    target = (torch.rand(batch, 3, nets['g'].size, nets['g'].size, generator=gen) * 2 - 1).to(device)
+    params = [p for m in nets.values() for p in m.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        img = Forward_Inference_3_Encoder(photo, render, wrapped['e_tsr'], wrapped['e_w'], wrapped['e_wp'], wrapped['g'])
+        (img - target).abs().mean().backward()
+
     return step, (photo, render)
 
 
@@ -185,6 +211,21 @@ def main():
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl['batch']
     nets = build_models(wl['size'], device)
+    if args.workload == 'train256':
+        step, inputs = make_train_step(nets, batch, device, rank, world)
+        dt = timed(step, args.steps, args.warmup, world)
+        if rank == 0:
+            print(json.dumps({
+                'metric': '(photo,render) pairs/sec (forward+backward)', 'value': world * batch * args.steps / dt,
+                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': f"train256: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
+                           'image_size': wl['size'], 'parallelism': f'dp{world} (DDP, 256 MiB buckets)' if world > 1 else 'single GPU'}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     step, inputs = make_step(nets, batch, device, rank)
 
     # headline kernel: the last (largest) blur of the workload; timed with HIP events inside the timed region
