@@ -49,6 +49,8 @@ def lib():
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
     _sig(L.fmgan_modconv_wgrad_workspace_bytes, [i] * 5, ll)
     _sig(L.fmgan_modconv_wgrad_f32, [vp] * 5 + [i] * 5 + [f, vp, ll, vp])
+    _sig(L.fmgan_images_to_tensor, [vp, vp, i, i, i, f, f, vp])
+    _sig(L.fmgan_tensor_to_images, [vp, vp, i, i, i, f, f, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
     if L.fmgan_abi_version() != 1:
         raise RuntimeError('libfmgan_hip.so ABI version mismatch')
@@ -299,4 +301,30 @@ def torgb(x, weight, style, bias, skip, scale):
         check(lib().fmgan_torgb_f32(ptr(x), ptr(weight), ptr(style), ptr(bias), ptr(sk), ptr(out), b, cin, cout, h * w,
                                     float(scale), stream), 'torgb')
         _observer.end(tok)
+    return out
+
+
+def images_to_tensor(images, mean=0.5, std=0.5):
+    """uint8 [B,H,W,3] (GPU) -> float32 [B,3,H,W] = ((images/255) - mean)/std: ToTensor + Normalize in one pass."""
+    require_gpu(images, 'images')
+    if images.dtype != torch.uint8 or images.ndim != 4 or images.shape[-1] != 3:
+        raise RuntimeError('images_to_tensor: expected a uint8 [B,H,W,3] tensor')
+    x = images.contiguous()
+    b, h, w, _ = x.shape
+    out = torch.empty((b, 3, h, w), dtype=torch.float32, device=x.device)
+    with on_device(x) as stream:
+        check(lib().fmgan_images_to_tensor(ptr(x), ptr(out), b, h, w, float(mean), float(std), stream), 'images_to_tensor')
+    return out
+
+
+def tensor_to_images(tensor, cent=1.0, factor=255.0 / 2.0):
+    """float32 [B,3,H,W] (GPU) -> uint8 [B,H,W,3] = uint8((clip(t,-1,1)+cent)*factor): tensor2im for the whole batch."""
+    require_gpu(tensor, 'tensor')
+    if tensor.dtype != torch.float32 or tensor.ndim != 4 or tensor.shape[1] != 3:
+        raise RuntimeError('tensor_to_images: expected a float32 [B,3,H,W] tensor')
+    x = tensor.contiguous()
+    b, _, h, w = x.shape
+    out = torch.empty((b, h, w, 3), dtype=torch.uint8, device=x.device)
+    with on_device(x) as stream:
+        check(lib().fmgan_tensor_to_images(ptr(x), ptr(out), b, h, w, float(cent), float(factor), stream), 'tensor_to_images')
     return out

@@ -24,6 +24,8 @@
  *   fmgan_modconv2d        <- ModulatedConv2d.forward  stylegan2.py:250-298
  *                             (F.conv2d / F.conv_transpose2d with groups=batch)
  *   fmgan_torgb            <- ToRGB.forward            stylegan2.py:389-404
+ *   fmgan_images_to_tensor <- transforms.ToTensor()+Normalize   train_3_encoder.py:233-239
+ *   fmgan_tensor_to_images <- tensor2im                 Evaluation/visual_eval.py:24-38
  */
 #ifndef FMGAN_HIP_H
 #define FMGAN_HIP_H
@@ -198,6 +200,19 @@ int fmgan_modconv_wgrad_f32(const float *go, const float *demod, const float *x,
 int fmgan_torgb_f32(const float *in, const float *weight, const float *style,
                     const float *bias, const float *skip, float *out,
                     int batch, int cin, int cout, int hw, float scale, void *stream);
+
+/*
+ * The steps either side of the path, 3-channel images:
+ *   fmgan_images_to_tensor: in uint8 [batch,h,w,3] -> out f32 [batch,3,h,w] = ((in/255) - mean) / std
+ *       == transforms.ToTensor() + Normalize(mean, std) (train_3_encoder.py:233-239; Resize(size) is the identity
+ *       for the 256^2 datasets of the reference and is not provided)
+ *   fmgan_tensor_to_images: in f32 [batch,3,h,w] -> out uint8 [batch,h,w,3] = (uint8)((clip(in,-1,1) + cent) * factor)
+ *       == tensor2im (Evaluation/visual_eval.py:24-38), for every image of the batch.
+ */
+int fmgan_images_to_tensor(const unsigned char *in, float *out, int batch, int h, int w,
+                           float mean, float stdv, void *stream);
+int fmgan_tensor_to_images(const float *in, unsigned char *out, int batch, int h, int w,
+                           float cent, float factor, void *stream);
 
 #ifdef __cplusplus
 }

@@ -272,3 +272,21 @@ def discriminator_forward(sd, x, size, blur_kernel=(1, 3, 3, 1)):
     out = out.view(batch, -1)
     out = equal_linear(out, sd['final_linear.0.weight'], sd['final_linear.0.bias'], activation=True)
     return equal_linear(out, sd['final_linear.1.weight'], sd['final_linear.1.bias'])
+
+
+# --------------------------------------------------------------------------- either side of the path (§8 f-4)
+def images_to_tensor(images_u8_hwc, mean=0.5, std=0.5):
+    """transforms.ToTensor() (HWC uint8 -> CHW float / 255) then Normalize(mean, std) = (t - mean) / std
+    (train_3_encoder.py:233-239), float32 arithmetic in that order."""
+    t = images_u8_hwc.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    return t.sub(mean).div(std)
+
+
+def tensor2im_batch(image_tensor, cent=1.0, factor=255.0 / 2.0):
+    """tensor2im, Evaluation/visual_eval.py:24-38, applied to every sample: clip to [-1,1], CHW -> HWC,
+    (x + cent) * factor in float32, astype(uint8) (truncation)."""
+    import numpy as np
+    a = image_tensor.cpu().float().numpy()
+    a = np.clip(a, a_min=-1, a_max=1)
+    a = (np.transpose(a, (0, 2, 3, 1)) + np.float32(cent)) * np.float32(factor)
+    return a.astype(np.uint8)

@@ -133,3 +133,15 @@ DISCRIMINATOR_CASES = [
     dict(name='d64', size=64, b=4),
     dict(name='d256', size=256, b=2),
 ]
+
+TENSOR2IM_CASES = [
+    dict(name='t2i_64', shape=(2, 3, 64, 64)),
+    dict(name='t2i_ragged', shape=(1, 3, 19, 23)),
+]
+
+
+def tensor2im_input(c):
+    """Values inside and outside [-1,1] plus the edge values of the clip and of the uint8 truncation."""
+    x = synth.tensor(c['name'] + '/x', c['shape'], scale=0.8)
+    x.view(-1)[:8] = torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, 0.999999, -0.999999, 0.00392])
+    return x

@@ -259,3 +259,42 @@ def test_noise_bias_act_matches_unfused_bitwise():
         ref = fused_leaky_relu(x + nw * nz, bias)
         y = _native.noise_bias_act(x, nz, nw, bias, 0.2, 2 ** 0.5)
         assert torch.equal(y, ref)
+
+
+# ------------------------------------------------------------------------------------------------ §8 f-4: image I/O
+def test_images_to_tensor_bit_exact():
+    from Util.image_io import images_to_tensor
+    from oracle import torch_oracle as T
+    g = torch.Generator().manual_seed(3)
+    for shape in ((2, 256, 256, 3), (3, 17, 31, 3), (1, 1024, 1024, 3)):
+        u8 = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        u8.view(-1)[:256] = torch.arange(256, dtype=torch.uint8)          # every byte value
+        y = images_to_tensor(u8.to(dev()))
+        ref = T.images_to_tensor(u8)
+        assert y.shape == ref.shape and torch.equal(y.cpu(), ref)
+    with pytest.raises(RuntimeError):
+        images_to_tensor(torch.zeros(1, 4, 4, 3, dtype=torch.uint8))       # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize('c', cases.TENSOR2IM_CASES, ids=lambda c: c['name'])
+def test_tensor2im_golden(c, golden):
+    from Evaluation.visual_eval import tensor2im
+    ref = golden('image_io')[c['name'] + '/im']
+    np.testing.assert_array_equal(tensor2im(cases.tensor2im_input(c).to(dev())), ref)
+
+
+def test_tensor2im_bit_exact():
+    from Evaluation.visual_eval import tensor2im, tensor2im_batch
+    from oracle import torch_oracle as T
+    for shape in ((2, 3, 64, 64), (3, 3, 19, 23), (1, 3, 1024, 1024)):
+        x = synth.tensor(f't2i/{shape}', shape, scale=0.8)
+        x.view(-1)[:8] = torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, 0.999999, -0.999999, 0.00392])
+        ref = T.tensor2im_batch(x)
+        y = tensor2im_batch(x.to(dev()))
+        np.testing.assert_array_equal(y.cpu().numpy(), ref)
+        np.testing.assert_array_equal(tensor2im(x.to(dev())), ref[0])
+    # round trip through the input converter: bytes -> [-1,1] -> bytes is the identity up to the truncation bias
+    u8 = torch.randint(0, 256, (1, 32, 32, 3), dtype=torch.uint8)
+    from Util.image_io import images_to_tensor
+    back = tensor2im_batch(images_to_tensor(u8.to(dev()))).cpu()
+    assert int((back.int() - u8.int()).abs().max()) <= 1

@@ -186,3 +186,9 @@ def test_discriminator_oracle(c, golden):
         y = T.discriminator_forward(sd, x, c['size'])
     ref = g[c['name'] + '/out']
     np.testing.assert_allclose(y.numpy(), ref, atol=1e-4 * max(1.0, np.abs(ref).max()), rtol=1e-4)
+
+
+@pytest.mark.parametrize('c', cases.TENSOR2IM_CASES, ids=lambda c: c['name'])
+def test_tensor2im_oracle(c, golden):
+    ref = golden('image_io')[c['name'] + '/im']
+    np.testing.assert_array_equal(T.tensor2im_batch(cases.tensor2im_input(c))[0], ref)

@@ -227,10 +227,25 @@ def gen_discriminator():
     print('discriminator', len(out))
 
 
+def gen_image_io():
+    """tensor2im of the reference (Evaluation/visual_eval.py:24-38; numpy only — `imageio` is stubbed, it is used by
+    the GIF writers, not by tensor2im).  transforms.ToTensor()/Normalize live in torchvision, which is not installed:
+    the input-side converter is pinned by its documented formula only."""
+    sys.modules.setdefault('imageio', types.ModuleType('imageio'))
+    from Evaluation import visual_eval
+    out = {}
+    for c in cases.TENSOR2IM_CASES:
+        x = cases.tensor2im_input(c)
+        out[c['name'] + '/im'] = visual_eval.tensor2im(x)
+    np.savez_compressed(os.path.join(OUT, 'image_io.npz'), **out)
+    print('image_io', len(out))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['upfirdn2d', 'fused_act', 'modules', 'generator', 'e2e', 'discriminator']
+    which = sys.argv[1:] or ['upfirdn2d', 'fused_act', 'modules', 'generator', 'e2e', 'discriminator', 'image_io']
     for w in which:
         {'upfirdn2d': gen_upfirdn2d, 'fused_act': gen_fused_act, 'modules': gen_modules,
-         'generator': gen_generator, 'e2e': gen_encoders_e2e, 'discriminator': gen_discriminator}[w]()
+         'generator': gen_generator, 'e2e': gen_encoders_e2e, 'discriminator': gen_discriminator,
+         'image_io': gen_image_io}[w]()
