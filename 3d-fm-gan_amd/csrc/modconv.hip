@@ -128,6 +128,9 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // MODE 1: transposed stride-2 3x3. Position (m,n) owns the 2x2 output quad (2m+py, 2n+px); its four phases
 //         use 4+2+2+1 = 9 taps of the same staged weights and only 4 distinct input offsets:
 //         out[2m+py, 2n+px] += w[ky][kx] * in[m - ky/2, n - kx/2],  ky = py (mod 2), kx = px (mod 2).
+// (A single-barrier variant — LDS double-buffered, the fill of chunk c+1 sliced between chunk c's MFMA stages — was
+// built and measured: 95 vs 121 TFLOP/s on the 128x128 tile.  It halves the co-resident blocks per CU and puts the
+// staging instructions of the only remaining wave per SIMD in front of its own MFMAs.  Not kept.)
 template <int MODE, int RM, int RNP, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   constexpr int KC = MC_KC;
@@ -215,33 +218,73 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   }
   float xv[NU][KC];
   f32x4 wv[NWV];
+  // Fast path: buffer loads.  The per-thread byte offsets are fixed for the whole K loop (voffset), the chunk only
+  // moves a scalar (soffset), and the hardware range check returns 0 for patch slots that fall outside the image
+  // (their voffset is parked past the end) — no per-load 64-bit address math, no branches.  A partial last chunk
+  // (cin not a multiple of 8) takes the guarded path.
+  // (An ablation showed the MFMA stages alone reach 140 TFLOP/s and the staging INSTRUCTIONS, not the bytes, are
+  // what the co-resident block has to hide.)
+  const bool fastw = wvec && o0 + BM <= p.cout && (long long)p.cin * 9 * p.cout * 4 < (1LL << 32);
+  const bool fastx = (long long)seg_nb * p.cin * hw * 4 < (1LL << 32);
+  const unsigned w_bytes = (unsigned)((long long)p.cin * 9 * p.cout * 4);   // (the range check ignores soffset)
+  const unsigned x_bytes = (unsigned)((long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, w_bytes, 0x00020000);
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b0), 0, x_bytes, 0x00020000);
+  unsigned wofs[NWV], xofs[NU];
+#pragma unroll
+  for (int j = 0; j < NWV; ++j) {
+    const int idx = tid + 256 * j;
+    const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+    wofs[j] = idx < KC * 9 * (BM / 4) ? (unsigned)((row * p.cout + o0 + c4 * 4) * 4) : 0xFFFFFFF0u;
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) xofs[u] = inb[u] ? (unsigned)gofs[u] * 4u : 0xFFFFFFF0u;
   auto issue = [&](int i0) {
+    if (fastw && i0 + KC <= i_end) {
+      const unsigned soff = (unsigned)(i0 * 9 * p.cout * 4);
 #pragma unroll
-    for (int j = 0; j < NWV; ++j) {
-      const int idx = tid + 256 * j;
-      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-      const int i = i0 + row / 9, o = o0 + c4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < KC * 9 * (BM / 4) && i < i_end) {
-        const float* src = p.wt + ((long long)i * 9 + row % 9) * p.cout + o;
-        if (wvec && o + 3 < p.cout) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-          if (o + 0 < p.cout) v.x = src[0];
-          if (o + 1 < p.cout) v.y = src[1];
-          if (o + 2 < p.cout) v.z = src[2];
-          if (o + 3 < p.cout) v.w = src[3];
-        }
+      for (int j = 0; j < NWV; ++j) {
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wofs[j], soff, 0);
+        wv[j] = __builtin_bit_cast(f32x4, t);
       }
-      wv[j] = v;
-    }
+    } else {
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
+      for (int j = 0; j < NWV; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+        const int i = i0 + row / 9, o = o0 + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < KC * 9 * (BM / 4) && i < i_end) {
+          const float* src = p.wt + ((long long)i * 9 + row % 9) * p.cout + o;
+          if (wvec && o + 3 < p.cout) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+            if (o + 0 < p.cout) v.x = src[0];
+            if (o + 1 < p.cout) v.y = src[1];
+            if (o + 2 < p.cout) v.z = src[2];
+            if (o + 3 < p.cout) v.w = src[3];
+          }
+        }
+        wv[j] = v;
+      }
+    }
+    if (fastx && i0 + KC <= i_end) {
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const int i = i0 + kc;
-        xv[u][kc] = (inb[u] && i < i_end) ? in_b0[gofs[u] + i * hw] : 0.f;
+        const unsigned soff = (unsigned)((i0 + kc) * hw * 4);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          xv[u][kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, xofs[u], soff, 0));
       }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int i = i0 + kc;
+          xv[u][kc] = (inb[u] && i < i_end) ? in_b0[gofs[u] + i * hw] : 0.f;
+        }
+    }
   };
   auto commit = [&](int i0) {
 #pragma unroll

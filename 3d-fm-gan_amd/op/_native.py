@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libfmgan_hip.so')
+LIB_PATH = os.environ.get('FMGAN_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libfmgan_hip.so')
 
 F32, F64, F16 = 0, 1, 2
 _DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16}
