@@ -47,7 +47,7 @@ def main(out):
     # steady state: kernels between the last two launches of the headline blur = one full step
     for f in find(os.path.join(out, 'trace'), '*kernel_trace.csv'):
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-        marks = [i for i, r in enumerate(rows) if 'ufd_rowmarch_f32<4>' in r['Kernel_Name']]
+        marks = [i for i, r in enumerate(rows) if 'ufd_rowmarch_f32<4' in r['Kernel_Name']]
         big = max((int(rows[i]['Grid_Size_X']) for i in marks), default=0)
         marks = [i for i in marks if int(rows[i]['Grid_Size_X']) == big]
         if len(marks) >= 3:
