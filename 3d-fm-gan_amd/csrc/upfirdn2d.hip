@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256) void ufd_generic(const T* __restrict__ in, con
 struct RMParams {
   int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw;
   long long in_plane_stride; int in_row_stride;
+  // optional StyledConv epilogue fused into the store (stylegan2.py:371-373): lrelu((y + nw*noise) + bias[c]) * scale
+  const float* noise; const float* noise_weight; const float* bias;
+  int fuse, channels, noise_batch; float alpha, act_scale;
   int th;       // output rows per wave, multiple of 4
   int strips;   // 64*VEC-column strips per row
   int tiles_y;  // row tiles per plane
@@ -156,10 +159,16 @@ __device__ __forceinline__ void finish_row(Row<VEC>& r, const RawRow<VEC>& raw, 
   }
 }
 
+struct RowEpilogue {   // wave-uniform
+  const float* noise_plane;   // noise of this plane's sample (nullptr: none)
+  float nw, bv, alpha, scale;
+  bool on;
+};
+
 template <int VEC, bool NT = false>
 __device__ __forceinline__ void emit_row(float* __restrict__ pout, int oy, int oy_end, int out_w, int c0,
                                          const float (&kf)[4][4], const Row<VEC>& r0, const Row<VEC>& r1,
-                                         const Row<VEC>& r2, const Row<VEC>& r3) {
+                                         const Row<VEC>& r2, const Row<VEC>& r3, const RowEpilogue& ep) {
   if (oy >= oy_end) return;  // wave-uniform
   float acc[VEC];
 #pragma unroll
@@ -174,6 +183,36 @@ __device__ __forceinline__ void emit_row(float* __restrict__ pout, int oy, int o
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx) v = fmaf(r3.v[e + kx], kf[3][kx], v);
     acc[e] = v;
+  }
+  if (ep.on) {
+    // same roundings as fmgan_noise_bias_act_f32: (y + nw*n) + b, select, *alpha, *scale — no FMA contraction
+    float nz[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) nz[e] = 0.f;
+    if (ep.noise_plane) {   // wave-uniform; one vector load per lane (rows of the output are dword-aligned at least)
+      const float* np = ep.noise_plane + (long long)oy * out_w + c0;
+      if (c0 + VEC <= out_w) {
+        if constexpr (VEC == 4) {
+          const f32x4_u t = *reinterpret_cast<const f32x4_u*>(np);
+          nz[0] = t.x; nz[1] = t.y; nz[2] = t.z; nz[3] = t.w;
+        } else if constexpr (VEC == 2) {
+          const f32x2_u t = *reinterpret_cast<const f32x2_u*>(np);
+          nz[0] = t.x; nz[1] = t.y;
+        } else {
+          nz[0] = np[0];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (c0 + e < out_w) nz[e] = np[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float n = nz[e];
+      float v = __fadd_rn(__fadd_rn(acc[e], __fmul_rn(ep.nw, n)), ep.bv);
+      acc[e] = __fmul_rn(v > 0.f ? v : __fmul_rn(v, ep.alpha), ep.scale);
+    }
   }
   float* op = pout + (long long)oy * out_w + c0;
   if (c0 + VEC <= out_w) {
@@ -233,6 +272,15 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
     pmask |= (a0 + e >= 0 && a0 + e < p.in_w) ? 1u << e : 0u;
     xmask |= (a0 + 64 * VEC + e >= 0 && a0 + 64 * VEC + e < p.in_w) ? 1u << e : 0u;
   }
+  RowEpilogue ep{};
+  ep.on = p.fuse != 0;
+  if (ep.on) {
+    const int ch = (int)(plane % p.channels), smp = (int)(plane / p.channels);
+    ep.nw = (p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
+    ep.bv = p.bias ? p.bias[ch] : 0.f;
+    ep.alpha = p.alpha; ep.scale = p.act_scale;
+    ep.noise_plane = p.noise ? p.noise + (long long)(p.noise_batch == 1 ? 0 : smp) * p.out_h * p.out_w : nullptr;
+  }
   const float* lo = in;
   const float* hi = in + ((long long)(p.planes - 1) * p.in_plane_stride + (long long)(p.in_h - 1) * p.in_row_stride + p.in_w);
 #define ISSUE(raw, k, need) issue_row<VEC>(raw, pin, iy0 + (k), need, p.in_h, p.in_w, p.in_row_stride, a0, lane, lo, hi)
@@ -246,13 +294,13 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
     const int oy = oy0 + r;
     if (oy >= oy_end) break;  // wave-uniform
     FINISH(w3, rb); ISSUE(rb, r + 5, oy + 2 < oy_end);
-    emit_row<VEC, NT>(pout, oy + 0, oy_end, p.out_w, c0, kf, w0, w1, w2, w3);
+    emit_row<VEC, NT>(pout, oy + 0, oy_end, p.out_w, c0, kf, w0, w1, w2, w3, ep);
     FINISH(w0, ra); ISSUE(ra, r + 6, oy + 3 < oy_end);
-    emit_row<VEC, NT>(pout, oy + 1, oy_end, p.out_w, c0, kf, w1, w2, w3, w0);
+    emit_row<VEC, NT>(pout, oy + 1, oy_end, p.out_w, c0, kf, w1, w2, w3, w0, ep);
     FINISH(w1, rb); ISSUE(rb, r + 7, oy + 4 < oy_end && r + 4 < p.th);
-    emit_row<VEC, NT>(pout, oy + 2, oy_end, p.out_w, c0, kf, w2, w3, w0, w1);
+    emit_row<VEC, NT>(pout, oy + 2, oy_end, p.out_w, c0, kf, w2, w3, w0, w1, ep);
     FINISH(w2, ra); ISSUE(ra, r + 8, oy + 5 < oy_end && r + 4 < p.th);
-    emit_row<VEC, NT>(pout, oy + 3, oy_end, p.out_w, c0, kf, w3, w0, w1, w2);
+    emit_row<VEC, NT>(pout, oy + 3, oy_end, p.out_w, c0, kf, w3, w0, w1, w2, ep);
   }
 #undef ISSUE
 #undef FINISH
@@ -388,8 +436,18 @@ bool rowmarch_ok(int dtype, const UfdParams& p) {
          p.kh <= 4 && p.kw <= 4 && p.out_w >= 64 && p.out_h >= 4;
 }
 
-int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
-  RMParams r;
+struct UfdEpilogue {
+  const float* noise; const float* noise_weight; const float* bias;
+  int channels, noise_batch; float alpha, act_scale;
+};
+
+int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s,
+                    const UfdEpilogue* ep = nullptr) {
+  RMParams r{};
+  if (ep) {
+    r.fuse = 1; r.noise = ep->noise; r.noise_weight = ep->noise_weight; r.bias = ep->bias;
+    r.channels = ep->channels; r.noise_batch = ep->noise_batch; r.alpha = ep->alpha; r.act_scale = ep->act_scale;
+  }
   r.planes = p.major; r.in_h = p.in_h; r.in_w = p.in_w; r.out_h = p.out_h; r.out_w = p.out_w;
   r.pad_x0 = p.pad_x0; r.pad_y0 = p.pad_y0; r.kh = p.kh; r.kw = p.kw;
   r.in_plane_stride = p.in_plane_stride; r.in_row_stride = p.in_row_stride;
@@ -534,6 +592,31 @@ extern "C" int fmgan_upfirdn2d_strided(int dtype, const void* input, const void*
     default:
       return FMGAN_EUNSUPPORTED;
   }
+}
+
+extern "C" int fmgan_blur_noise_bias_act_f32(const float* input, const float* kernel, float* out, int batch,
+                                             int channels, int in_h, int in_w, long long in_plane_stride,
+                                             int in_row_stride, int kernel_h, int kernel_w, int pad_x0, int pad_x1,
+                                             int pad_y0, int pad_y1, const float* noise, const float* noise_weight,
+                                             const float* bias, int noise_batch, float alpha, float act_scale,
+                                             void* stream) {
+  if (batch < 0 || channels <= 0) return FMGAN_EINVAL;
+  const long long major = (long long)batch * channels;
+  if (major > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+  int st = validate(FMGAN_F32, (int)major, in_h, in_w, 1, kernel_h, kernel_w, 1, 1, 1, 1);
+  if (st != FMGAN_OK) return st;
+  if (in_row_stride < in_w || in_plane_stride < (long long)(in_h - 1) * in_row_stride + in_w) return FMGAN_EINVAL;
+  if (noise && noise_batch != 1 && noise_batch != batch) return FMGAN_EINVAL;
+  UfdParams p{(int)major, in_h, in_w, 1, kernel_h, kernel_w, 1, 1, 1, 1, pad_x0, pad_y0, 0, 0, in_plane_stride,
+              in_row_stride};
+  fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, &p.out_h, &p.out_w);
+  if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
+  if (major == 0) return FMGAN_OK;
+  if (!input || !kernel || !out) return FMGAN_EINVAL;
+  if (!rowmarch_ok(FMGAN_F32, p)) return FMGAN_EUNSUPPORTED;   // small planes: the caller keeps the two-pass form
+  if ((long long)in_h * in_row_stride > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+  UfdEpilogue ep{noise, noise_weight, bias, channels, noise_batch, alpha, act_scale};
+  return launch_rowmarch(input, kernel, out, p, (hipStream_t)stream, &ep);
 }
 
 extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel, void* out, int major, int in_h,

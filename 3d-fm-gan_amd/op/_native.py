@@ -41,6 +41,7 @@ def lib():
     _sig(L.fmgan_upfirdn2d_out_size, [i] * 12 + [ctypes.POINTER(i)] * 2)
     _sig(L.fmgan_upfirdn2d, [i, vp, vp, vp] + [i] * 15 + [vp])
     _sig(L.fmgan_upfirdn2d_strided, [i, vp, vp, vp] + [i] * 4 + [ll, i] + [i] * 11 + [vp])
+    _sig(L.fmgan_blur_noise_bias_act_f32, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6 + [vp] * 3 + [i, f, f, vp])
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
@@ -160,6 +161,31 @@ def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_strid
                                             row_stride, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, -1, stream),
               'upfirdn2d_strided')
         _observer.end(tok)
+    return out
+
+
+def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_stride, row_stride, kernel, pad, noise,
+                        noise_weight, bias, alpha, scale):
+    """blur -> (+noise) -> +bias -> lrelu*scale in one pass over a strided f32 input; returns [B,C,out_h,out_w] or None
+    when the shape is not served by the row-march kernel (the caller then uses the two-pass form)."""
+    k = kernel.contiguous()
+    kh, kw = k.shape
+    pad0, pad1 = pad
+    out_h, out_w = upfirdn2d_out_size(in_h, in_w, kh, kw, 1, 1, 1, 1, pad0, pad1, pad0, pad1)
+    if out_w < 64 or out_h < 4:
+        return None
+    out = torch.empty((batch, channels, out_h, out_w), dtype=torch.float32, device=device)
+    nz = noise.contiguous() if noise is not None else None
+    with on_device(out) as stream:
+        tok = _observer.begin('upfirdn2d', (batch * channels, in_h, in_w, out_h, out_w, 1, 1, 4))
+        st = lib().fmgan_blur_noise_bias_act_f32(in_ptr, ptr(k), ptr(out), batch, channels, in_h, in_w, plane_stride,
+                                                 row_stride, kh, kw, pad0, pad1, pad0, pad1, ptr(nz), ptr(noise_weight),
+                                                 ptr(bias), 1 if nz is None else nz.shape[0], float(alpha), float(scale),
+                                                 stream)
+        _observer.end(tok)
+    if st == -2:
+        return None
+    check(st, 'blur_noise_bias_act')
     return out
 
 

@@ -262,10 +262,14 @@ class StyledConv(nn.Module):
             pad0, pad1 = conv.blur.pad
             buf, p0, ps, rs = _native.aligned_rows_buffer(b, c, 2 * h + 1, 2 * w + 1, pad0, input.device)
             _native.modconv2d(input, conv.mfma_weight(), s, demod, 1, strided_out=(p0, ps, rs))
-            out = _native.upfirdn2d_strided(p0, input.device, b * c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
-                                            pad0, pad1, pad0, pad1).view(b, c, oh, ow)
+            out = _native.blur_noise_bias_act(p0, input.device, b, c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
+                                              (pad0, pad1), noise, self.noise.weight, act.bias, act.negative_slope,
+                                              act.scale)          # blur + noise + bias + act in the blur's store
+            if out is None:   # small planes: blur from LDS, then the one-pass epilogue
+                out = _native.upfirdn2d_strided(p0, input.device, b * c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
+                                                pad0, pad1, pad0, pad1).view(b, c, oh, ow)
+                out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)
             del buf
-            out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)
         else:
             out = _native.modconv2d(input, conv.mfma_weight(), s, demod, 0, noise=noise,
                                     noise_weight=self.noise.weight, bias=act.bias, fuse_act=True,

@@ -261,6 +261,7 @@ def main():
     summ = timer.summary()
     if (('upfirdn2d', head) in summ):
         ms, n = summ[('upfirdn2d', head)]
+        # algorithmic bytes of the blur: input + output (the fused noise row adds 1/C of the output and is not counted)
         bytes_alg = 4.0 * head[0] * (head[1] * head[2] + head[3] * head[4])
         ach = bytes_alg / (ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
@@ -269,10 +270,33 @@ def main():
             rec = json.load(open(tf))       # PMC passes cannot run inside this process: committed rocprofv3 result
             traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/r01_headline_traffic.json (' + rec['source'] + ')'
 
-        out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_rowmarch_f32<4> [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
+        out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_rowmarch_f32<4> (blur + fused noise/bias/lrelu store) [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                            'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': ms, 'launches': n,
                            'algorithmic_bytes': bytes_alg}
+
+    # The reference-API op itself (op.upfirdn2d on a contiguous [B*C,2H+1,2W+1] tensor, no fused epilogue), standalone:
+    # the in-situ kernel above additionally applies noise + bias + leaky ReLU in its store, which replaces a second
+    # 2.1 GB elementwise pass but costs ~50 us of the blur's own time.
+    if args.workload == 'pairs1024' and 'roofline' in out:
+        from op import upfirdn2d as op_upfirdn2d
+        g = nets['g']
+        xin = torch.randn(batch, g.channels[r], r + 1, r + 1, device=device)
+        kern = g.convs[-2].conv.blur.kernel
+        for _ in range(3):
+            op_upfirdn2d(xin, kern, pad=g.convs[-2].conv.blur.pad)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            op_upfirdn2d(xin, kern, pad=g.convs[-2].conv.blur.pad)
+        e1.record()
+        e1.synchronize()
+        ms_op = e0.elapsed_time(e1) / 10
+        ach_op = out['roofline']['algorithmic_bytes'] / (ms_op * 1e-3) / 1e9
+        out['roofline_upfirdn2d_op'] = {'bound': 'hbm', 'kernel': 'op.upfirdn2d (contiguous input, no epilogue), 10 back-to-back launches',
+                                        'achieved': ach_op, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach_op / HBM_PEAK_GBS,
+                                        'avg_launch_ms': ms_op}
+        del xin
 
     # per-kernel breakdown (separate, fully instrumented pass; not part of `value`)
     full = LaunchTimer(lambda name, info: True)

@@ -101,6 +101,23 @@ int fmgan_upfirdn2d_strided(int dtype, const void *input, const void *kernel, vo
                             int force_path, void *stream);
 
 /*
+ * The tail of an upsampling StyledConv in one pass (stylegan2.py:279 + 371-373): 4x4 (or smaller) FIR blur of the
+ * transposed-conv result, then noise + bias + leaky ReLU * scale applied to the filtered value before it is stored:
+ *   out[b,c,y,x] = lrelu( (blur(in)[b,c,y,x] + noise_weight[0]*noise[b or 0,y,x]) + bias[c] ) * act_scale
+ * in [batch*channels planes, in_h, in_w] with element strides as in fmgan_upfirdn2d_strided; out contiguous
+ * [batch,channels,out_h,out_w]; noise [noise_batch (1|batch), out_h*out_w] or NULL; bias [channels] or NULL.
+ * Served by the row-march kernel only (out_w >= 64): FMGAN_EUNSUPPORTED otherwise — the caller then runs
+ * fmgan_upfirdn2d(_strided) followed by fmgan_noise_bias_act_f32, which gives bit-identical results.
+ */
+int fmgan_blur_noise_bias_act_f32(const float *input, const float *kernel, float *out,
+                                  int batch, int channels, int in_h, int in_w,
+                                  long long in_plane_stride, int in_row_stride,
+                                  int kernel_h, int kernel_w,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                  const float *noise, const float *noise_weight, const float *bias,
+                                  int noise_batch, float alpha, float act_scale, void *stream);
+
+/*
  * fused_bias_act: out[i] = act'(x[i] + bias[(i / step_b) % size_b]; refer[i]) * scale
  *   act*10+grad: 10,11 linear; 12 zero; 30 lrelu(x); 31 (refer>0 ? x : alpha*x); 32 zero
  *   (op/fused_bias_act_kernel.cu:36-45).  bias == NULL or size_b == 0: no bias;

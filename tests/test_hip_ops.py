@@ -112,6 +112,31 @@ def test_upfirdn2d_strided_input_matches_contiguous(shape, pad):
     assert torch.equal(y, ref.view_as(y))
 
 
+@pytest.mark.parametrize('cfg', [(2, 5, 64, 2), (1, 3, 129, 1), (3, 4, 100, 3), (1, 2, 300, 1)])
+def test_blur_with_fused_epilogue_matches_two_passes(cfg):
+    """fmgan_blur_noise_bias_act_f32 (noise + bias + lrelu folded into the blur's store) must equal the blur followed by
+    fmgan_noise_bias_act_f32 bit for bit — same roundings, same order."""
+    from op import _native
+    b, c, hw, nb = cfg
+    k = (cases.make_fir('blur4')).to(dev())
+    x = synth.tensor(f'fep/{cfg}/x', (b * c, 2 * hw + 1, 2 * hw + 1)).to(dev())
+    nz = synth.tensor(f'fep/{cfg}/n', (nb, 1, 2 * hw, 2 * hw)).to(dev())
+    nw = torch.tensor([0.37], device=dev())
+    bias = synth.tensor(f'fep/{cfg}/b', (c,)).to(dev())
+    buf, p0, ps, rs = _native.aligned_rows_buffer(b, c, 2 * hw + 1, 2 * hw + 1, 1, dev())
+    buf.fill_(float('nan'))
+    buf[:, :, 1:2 * hw + 2] = x
+    y2 = _native.upfirdn2d_strided(p0, dev(), b * c, 2 * hw + 1, 2 * hw + 1, ps, rs, k, 1, 1, 1, 1).view(b, c, 2 * hw, 2 * hw)
+    ref = _native.noise_bias_act(y2, nz, nw, bias, 0.2, 2 ** 0.5)
+    y = _native.blur_noise_bias_act(p0, dev(), b, c, 2 * hw + 1, 2 * hw + 1, ps, rs, k, (1, 1), nz, nw, bias, 0.2, 2 ** 0.5)
+    assert y is not None and torch.equal(y, ref)
+    # without noise / bias
+    y0 = _native.blur_noise_bias_act(p0, dev(), b, c, 2 * hw + 1, 2 * hw + 1, ps, rs, k, (1, 1), None, None, None, 0.2, 2 ** 0.5)
+    assert torch.equal(y0, _native.noise_bias_act(y2, None, None, None, 0.2, 2 ** 0.5))
+    # small planes are not served: the caller falls back
+    assert _native.blur_noise_bias_act(p0, dev(), b, c, 17, 17, ps, rs, k, (1, 1), None, None, None, 0.2, 1.0) is None
+
+
 def test_modconv_strided_output_matches_contiguous():
     from op import _native
     for (b, cin, cout, h, w) in ((2, 8, 40, 16, 16), (1, 16, 130, 9, 7), (9, 12, 20, 4, 4)):
