@@ -130,7 +130,11 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 //         out[2m+py, 2n+px] += w[ky][kx] * in[m - ky/2, n - kx/2],  ky = py (mod 2), kx = px (mod 2).
 // (A single-barrier variant — LDS double-buffered, the fill of chunk c+1 sliced between chunk c's MFMA stages — was
 // built and measured: 95 vs 121 TFLOP/s on the 128x128 tile.  It halves the co-resident blocks per CU and puts the
-// staging instructions of the only remaining wave per SIMD in front of its own MFMAs.  Not kept.)
+// staging instructions of the only remaining wave per SIMD in front of its own MFMAs.  Not kept.
+// Persistent tiles for the short-K layers (a block walks 2-8 tiles and loads the next tile's first chunk under the
+// current tile's last chunk / epilogue) were also measured: 56-88 vs 68-97 TFLOP/s on the 512^2-1024^2 layers —
+// holding the prefetched chunk across the epilogue spills 20-70 VGPRs, and the two co-resident blocks per SIMD
+// already overlap one block's prologue/epilogue with the other's MFMAs.  Not kept.)
 template <int MODE, int RM, int RNP, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   constexpr int KC = MC_KC;
