@@ -8,6 +8,7 @@ resize 13x faster (measured on MI355X: 14.9 -> 10.7 ms at B=8, 51.3 -> 32.0 ms a
 not provided.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -16,6 +17,12 @@ from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
 
 from .helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
 from stylegan2 import EqualLinear
+from Util.streams import overlap_ok, run_on, side_streams
+
+# Inference: the style heads are independent of each other and each ends in a tail of tiny launches (conv at 16^2 ... 1^2
+# + bias + LeakyReLU, ~25 kernels of a few microseconds) that cannot fill 256 CUs; heads are dealt round-robin onto
+# this many side streams so the tails overlap other heads' large first convs and the pyramid's lateral layers.
+HEAD_STREAMS = int(os.environ.get('FMGAN_PSP_STREAMS', '4'))
 
 _TAPS = {18: (3, 5, 7), 50: (6, 20, 23)}   # units whose outputs feed the pyramid (psp_encoders.py:105-108)
 
@@ -85,9 +92,22 @@ class GradualStyleEncoder(Module):
             if i in (t1, t2, t3):
                 feats[i] = x
         c1, c2, c3 = feats[t1], feats[t2], feats[t3]
-        latents = [self.styles[j](c3) for j in range(min(self.coarse_ind, self.style_count))]
+        joins = []
+        if HEAD_STREAMS > 1 and overlap_ok(x):
+            streams = side_streams(x.device, HEAD_STREAMS)
+
+            def head(j, feat):
+                join, out = run_on(streams[j % HEAD_STREAMS], self.styles[j], feat)
+                joins.append(join)
+                return out
+        else:
+            def head(j, feat):
+                return self.styles[j](feat)
+        latents = [head(j, c3) for j in range(min(self.coarse_ind, self.style_count))]
         p2 = self._upsample_add(c3, self.latlayer1(c2))
-        latents += [self.styles[j](p2) for j in range(self.coarse_ind, min(self.middle_ind, self.style_count))]
+        latents += [head(j, p2) for j in range(self.coarse_ind, min(self.middle_ind, self.style_count))]
         p1 = self._upsample_add(p2, self.latlayer2(c1))
-        latents += [self.styles[j](p1) for j in range(self.middle_ind, self.style_count)]
+        latents += [head(j, p1) for j in range(self.middle_ind, self.style_count)]
+        for join in joins:
+            join()
         return torch.stack(latents, dim=1)
