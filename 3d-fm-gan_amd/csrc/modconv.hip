@@ -24,6 +24,9 @@
 namespace {
 
 // ------------------------------------------------------------------ demod
+// PRE: W is the per-(o,i) sum of squared taps [cout][cin] (modconv_wsq_f32, cached with the weight) instead of the
+// raw weight — the same fma chains in the same order, so both variants give identical bits.
+template <bool PRE>
 __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict__ W,
                                                          const float* __restrict__ style,
                                                          float* __restrict__ demod, int batch, int cout, int cin,
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= cout) return;  // wave-uniform
-  const float* wo = W + (long long)o * cin * ktaps;
+  const float* wo = W + (long long)o * cin * (PRE ? 1 : ktaps);
   constexpr int MAXJ = 8;
   const bool cached = cin <= 64 * MAXJ;
   float wsq[MAXJ];
@@ -40,8 +43,11 @@ __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict
     for (int j = 0; j < MAXJ; ++j) {
       const int i = lane + 64 * j;
       float q = 0.f;
-      if (i < cin)
-        for (int t = 0; t < ktaps; ++t) { const float w = wo[i * ktaps + t]; q = fmaf(w, w, q); }
+      if (i < cin) {
+        if constexpr (PRE) q = wo[i];
+        else
+          for (int t = 0; t < ktaps; ++t) { const float w = wo[i * ktaps + t]; q = fmaf(w, w, q); }
+      }
       wsq[j] = q;
     }
   }
@@ -57,7 +63,9 @@ __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict
     } else {
       for (int i = lane; i < cin; i += 64) {
         float q = 0.f;
-        for (int t = 0; t < ktaps; ++t) { const float w = wo[i * ktaps + t]; q = fmaf(w, w, q); }
+        if constexpr (PRE) q = wo[i];
+        else
+          for (int t = 0; t < ktaps; ++t) { const float w = wo[i * ktaps + t]; q = fmaf(w, w, q); }
         const float m = sb[i];
         acc = fmaf(q, m * m, acc);
       }
@@ -65,6 +73,15 @@ __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) demod[(long long)b * cout + o] = 1.0f / sqrtf(scale * scale * acc + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void modconv_wsq_f32(const float* __restrict__ W, float* __restrict__ wsq,
+                                                       long long n, int ktaps) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+    float q = 0.f;
+    for (int t = 0; t < ktaps; ++t) { const float w = W[idx * ktaps + t]; q = fmaf(w, w, q); }
+    wsq[idx] = q;
   }
 }
 
@@ -106,6 +123,12 @@ struct MCParams {
   float* ws;
   const float* noise; const float* noise_weight; const float* bias;
   int noise_batch, fuse_act; float alpha, act_scale;
+  // ToRGB fused into the epilogue (MODE 0, one output-channel tile, no split-K): the block holds every channel of
+  // its pixels, so rgb[b,c,pix] = sum_o act[b,o,pix] * wmod[b,c,o] (+ bias + skip) is a reduction over
+  // the accumulator rows; `out` may then be null (last layer: the activation has no other consumer).
+  const float* rgb_wmod;   // [batch][3][cout] = rgb_scale * W[c,o] * rgb_style[b,o], rows >= rgb_c zero
+  const float* rgb_bias; const float* rgb_skip; float* rgb_out;
+  int rgb_c;
 };
 
 constexpr int MC_KC = 8;  // input channels per LDS chunk
@@ -135,8 +158,9 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // current tile's last chunk / epilogue) were also measured: 56-88 vs 68-97 TFLOP/s on the 512^2-1024^2 layers —
 // holding the prefetched chunk across the epilogue spills 20-70 VGPRs, and the two co-resident blocks per SIMD
 // already overlap one block's prologue/epilogue with the other's MFMAs.  Not kept.)
-template <int MODE, int RM, int RNP, int WM, int WN>
+template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false>
 __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
+  static_assert(!RGB || MODE == 0, "the RGB epilogue belongs to the plain conv");
   constexpr int KC = MC_KC;
   constexpr int BM = 32 * RM * WM;
   constexpr int NPH = MODE == 1 ? 4 : 1;   // output phases per position
@@ -395,47 +419,139 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
     }
   }
 
-  // ---- epilogue
-  const float nw = (p.fuse_act && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
+  // ---- epilogue.  All loads first (bias, demod, noise: clamped indices, no branches — a load inside a divergent
+  // `if` costs one full memory round trip per element, 64 of them in a row per thread), then arithmetic on the
+  // accumulators in place, then predicated stores.
   const bool partial = p.ksplit > 1;
+  const bool actf = p.fuse_act && !partial;
+  const bool use_demod = p.demod != nullptr && !partial;
+  const float nw = (actf && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
   float* dstbase = partial ? p.ws + (long long)ks * p.batch * p.cout * p.oh * p.ow : p.out;
   const long long dps = partial ? (long long)p.oh * p.ow : p.out_plane_stride;
   const int drs = partial ? p.ow : p.out_row_stride;
+  const int orow = o0 + wm * 32 * RM + 4 * khalf;     // this lane's first output channel; row r adds (r&3) + 8*(r>>2)
+  float bias_v[RM][16], dm[RM][16];
 #pragma unroll
-  for (int m = 0; m < RM; ++m) {
+  for (int m = 0; m < RM; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = o0 + wm * 32 * RM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      if (o >= p.cout) continue;
+      const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
+      bias_v[m][r] = (actf && p.bias) ? p.bias[oc] : 0.f;
+      dm[m][r] = 1.f;
+    }
 #pragma unroll
-      for (int g = 0; g < RNP; ++g) {
-        const int b = pos_b[g];
-        if (b >= p.batch) continue;
-        float* dplane = dstbase + ((long long)b * p.cout + o) * dps;
-        if constexpr (MODE != 1) {
-          const int y = pos_y[g], x = pos_x[g];
-          if (y >= p.oh || x >= p.ow) continue;
-          const int pix = y * p.ow + x;
-          float v = acc[m][g][0][r];
-          if (!partial) v = mc_epilogue(v, p, nw, b, o, pix);
-          dplane[(long long)y * drs + x] = v;
-        } else {
-          if (pos_y[g] >= seg_m_end || pos_x[g] >= seg_n_end) continue;
-          const int X = 2 * pos_x[g];
-          const float d = (!partial && p.demod) ? p.demod[(long long)b * p.cout + o] : 1.f;
+  for (int g = 0; g < RNP; ++g) {
+    const int b = pos_b[g], bc = min(b, p.batch - 1);
+    if (use_demod && (g == 0 || seg_nb > 1)) {        // tiles of one sample (every large layer) load demod once
+#pragma unroll
+      for (int m = 0; m < RM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dm[m][r] = p.demod[(long long)bc * p.cout + min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1)];
+    }
+    if constexpr (MODE != 1) {
+      const int y = pos_y[g], x = pos_x[g];
+      const bool vg = b < p.batch && y < p.oh && x < p.ow;
+      const int pix = vg ? y * p.ow + x : 0;
+      const float nz = (actf && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : bc) * p.oh * p.ow + pix]) : 0.f;
+      float* dpos = dstbase + (long long)bc * p.cout * dps + (long long)(vg ? y : 0) * drs + (vg ? x : 0);
+#pragma unroll
+      for (int m = 0; m < RM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+          float v = acc[m][g][0][r] * dm[m][r];
+          if (actf) {
+            v = __fadd_rn(__fadd_rn(v, nz), bias_v[m][r]);
+            v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
+          }
+          if constexpr (RGB) acc[m][g][0][r] = (vg && o < p.cout) ? v : 0.f;
+          if ((!RGB || dstbase) && vg && o < p.cout) dpos[(long long)o * dps] = v;
+        }
+    } else {
+      const bool vg = b < p.batch && pos_y[g] < seg_m_end && pos_x[g] < seg_n_end;
+      const int X = 2 * pos_x[g], Y0 = 2 * pos_y[g];
+      const bool pair = X + 1 < p.ow;
+      float* dpos = dstbase + (long long)bc * p.cout * dps + (long long)(vg ? Y0 : 0) * drs + (vg ? X : 0);
+#pragma unroll
+      for (int m = 0; m < RM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+          if (!(vg && o < p.cout)) continue;
+          float* dst = dpos + (long long)o * dps;
 #pragma unroll
           for (int py = 0; py < 2; ++py) {
-            const int Y = 2 * pos_y[g] + py;
-            if (Y >= p.oh || X >= p.ow) continue;
-            float* dst = dplane + (long long)Y * drs + X;
-            const float v0 = acc[m][g][py * 2][r] * d, v1 = acc[m][g][py * 2 + 1][r] * d;
-            if (X + 1 < p.ow) {
+            if (Y0 + py >= p.oh) continue;
+            const float v0 = acc[m][g][py * 2][r] * dm[m][r], v1 = acc[m][g][py * 2 + 1][r] * dm[m][r];
+            if (pair) {
               f32x2_u t; t.x = v0; t.y = v1;
-              *reinterpret_cast<f32x2_u*>(dst) = t;
+              *reinterpret_cast<f32x2_u*>(dst + (long long)py * drs) = t;
             } else {
-              dst[0] = v0;
+              dst[(long long)py * drs] = v0;
             }
           }
+        }
+    }
+  }
+  if constexpr (RGB) {
+    // second pass over the activated values (now in the accumulators): rgb = sum over rows of act * wmod, where
+    // wmod[b,c,o] = rgb_scale * W[c,o] * rgb_style[b,o]; rows of one position live in both lane halves (khalf) and,
+    // with WM = 2, in two waves: fixed-order reduction.
+    float rs[RNP][3];
+#pragma unroll
+    for (int g = 0; g < RNP; ++g) rs[g][0] = rs[g][1] = rs[g][2] = 0.f;
+    // (the host only fuses layers whose tiles hold one sample: b0 is the sample of every position of this block)
+    const float* wmod = p.rgb_wmod + (long long)min(b0, p.batch - 1) * 3 * p.cout;
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+      float rw[3][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rw[c][r] = wmod[c * p.cout + oc];
+      }
+#pragma unroll
+      for (int g = 0; g < RNP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) rs[g][c] = fmaf(acc[m][g][0][r], rw[c][r], rs[g][c]);
+    }
+#pragma unroll
+    for (int g = 0; g < RNP; ++g)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rs[g][c] += __shfl_xor(rs[g][c], 32, 64);
+    if constexpr (WM > 1) {
+      static_assert(WM == 2, "two output-channel waves at most");
+      __syncthreads();            // every wave is done with the last chunk's LDS operands
+      float* red = smem + ((wn * RNP) * 3) * 32;
+      if (wm == 1 && khalf == 0)
+#pragma unroll
+        for (int g = 0; g < RNP; ++g)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) red[(g * 3 + c) * 32 + l31] = rs[g][c];
+      __syncthreads();
+      if (wm == 0 && khalf == 0)
+#pragma unroll
+        for (int g = 0; g < RNP; ++g)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) rs[g][c] += red[(g * 3 + c) * 32 + l31];
+    }
+    if (wm == 0 && khalf == 0) {
+#pragma unroll
+      for (int g = 0; g < RNP; ++g) {
+        const int b = pos_b[g], y = pos_y[g], x = pos_x[g];
+        if (b >= p.batch || y >= p.oh || x >= p.ow) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (c >= p.rgb_c) continue;
+          const long long off = (((long long)b * p.rgb_c + c) * p.oh + y) * p.ow + x;
+          float v = rs[g][c];
+          if (p.rgb_bias) v = __fadd_rn(v, p.rgb_bias[c]);
+          if (p.rgb_skip) v = __fadd_rn(v, p.rgb_skip[off]);
+          p.rgb_out[off] = v;
         }
       }
     }
@@ -486,6 +602,7 @@ inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
 
 template <int MODE, int RM, int RNP, int WM, int WN>
 int launch_cfg(MCParams& p, hipStream_t s) {
+  if constexpr (MODE != 0) { if (p.rgb_out) return FMGAN_EUNSUPPORTED; }
   constexpr int BM = 32 * RM * WM, BN = 32 * RNP * WN;
   constexpr int SP = MODE == 2 ? 2 : 1;
   p.o_tiles = (p.cout + BM - 1) / BM;
@@ -501,6 +618,13 @@ int launch_cfg(MCParams& p, hipStream_t s) {
     if (f > patch) patch = f;
   }
   const size_t lds = sizeof(float) * ((size_t)MC_KC * 9 * BM + patch);
+  if constexpr (MODE == 0) {
+    if (p.rgb_out) {
+      if (p.o_tiles != 1 || p.ksplit != 1) return FMGAN_EUNSUPPORTED;
+      hipLaunchKernelGGL((modconv_mfma_f32<0, RM, RNP, WM, WN, true>), dim3((unsigned)blocks, 1), dim3(256), lds, s, p);
+      return fmgan_check_launch();
+    }
+  }
   hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RNP, WM, WN>), dim3((unsigned)blocks, p.ksplit), dim3(256), lds, s, p);
   return fmgan_check_launch();
 }
@@ -840,8 +964,28 @@ extern "C" int fmgan_modconv_demod_f32(const float* weight, const float* style, 
   if (batch < 0 || cout <= 0 || cin <= 0 || ktaps <= 0) return FMGAN_EINVAL;
   if (batch == 0) return FMGAN_OK;
   if (!weight || !style || !demod) return FMGAN_EINVAL;
-  hipLaunchKernelGGL(modconv_demod_f32, dim3((cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, weight, style, demod,
-                     batch, cout, cin, ktaps, scale, eps);
+  hipLaunchKernelGGL(modconv_demod_f32<false>, dim3((cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, weight, style,
+                     demod, batch, cout, cin, ktaps, scale, eps);
+  return fmgan_check_launch();
+}
+
+extern "C" int fmgan_modconv_wsq_f32(const float* weight, float* wsq, int cout, int cin, int ktaps, void* stream) {
+  if (cout <= 0 || cin <= 0 || ktaps <= 0) return FMGAN_EINVAL;
+  if (!weight || !wsq) return FMGAN_EINVAL;
+  const long long n = (long long)cout * cin;
+  long long blocks = (n + 255) / 256;
+  if (blocks > FMGAN_NUM_CU * 16) blocks = FMGAN_NUM_CU * 16;
+  hipLaunchKernelGGL(modconv_wsq_f32, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, weight, wsq, n, ktaps);
+  return fmgan_check_launch();
+}
+
+extern "C" int fmgan_modconv_demod_wsq_f32(const float* wsq, const float* style, float* demod, int batch, int cout,
+                                           int cin, float scale, float eps, void* stream) {
+  if (batch < 0 || cout <= 0 || cin <= 0) return FMGAN_EINVAL;
+  if (batch == 0) return FMGAN_OK;
+  if (!wsq || !style || !demod) return FMGAN_EINVAL;
+  hipLaunchKernelGGL(modconv_demod_f32<true>, dim3((cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, wsq, style, demod,
+                     batch, cout, cin, 1, scale, eps);
   return fmgan_check_launch();
 }
 
@@ -868,19 +1012,53 @@ extern "C" long long fmgan_modconv2d_workspace_bytes(int batch, int cin, int cou
   return (long long)ks * batch * cout * oh * ow * (long long)sizeof(float);
 }
 
-extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float* style, const float* demod,
-                                   float* out, int batch, int cin, int cout, int h, int w, int mode,
-                                   const float* noise, const float* noise_weight, const float* bias, int noise_batch,
-                                   int fuse_act, float alpha, float act_scale, long long out_plane_stride,
-                                   int out_row_stride, void* workspace, long long workspace_bytes, void* stream) {
+namespace {
+struct RgbArgs {
+  const float* wmod; const float* bias; const float* skip; float* out; int c;
+};
+
+bool rgb_fusable(int batch, int cin, int cout, int h, int w) {
+  const int cfg = pick_cfg(0, cout, (long long)batch * h * w);
+  int BM, BN;
+  cfg_dims(0, cfg, BM, BN);
+  (void)cin;
+  MCParams::Seg sg{0, 0, h, w};
+  plan_segment(sg, batch, BN);
+  // one output-channel tile, tiles of a single sample; the fused launch runs without split-K
+  return cfg <= 2 && cout <= BM && sg.nb == 1;
+}
+
+__global__ __launch_bounds__(256) void torgb_weight_mod_f32(const float* __restrict__ W, const float* __restrict__ style,
+                                                            float* __restrict__ wmod, int batch, int cout, int rgb_c,
+                                                            float scale) {
+  const int n = batch * 3 * cout;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const int o = idx % cout, c = (idx / cout) % 3, b = idx / (3 * cout);
+    wmod[idx] = c < rgb_c ? scale * W[c * cout + o] * style[(long long)b * cout + o] : 0.f;
+  }
+}
+
+int modconv2d_impl(const float* in, const float* wt, const float* style, const float* demod,
+                   float* out, int batch, int cin, int cout, int h, int w, int mode,
+                   const float* noise, const float* noise_weight, const float* bias, int noise_batch,
+                   int fuse_act, float alpha, float act_scale, long long out_plane_stride,
+                   int out_row_stride, void* workspace, long long workspace_bytes, void* stream, const RgbArgs* rgb) {
   if (batch < 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return FMGAN_EINVAL;
   if (mode < 0 || mode > 2) return FMGAN_EUNSUPPORTED;
   if (mode != 0 && fuse_act) return FMGAN_EUNSUPPORTED;  // the blur sits between conv and activation
   if (mode == 2 && (h < 3 || w < 3)) return FMGAN_EINVAL;
+  if (rgb) {
+    if (rgb->c < 1 || rgb->c > 3) return FMGAN_EUNSUPPORTED;
+    if (!rgb_fusable(batch, cin, cout, h, w)) return FMGAN_EUNSUPPORTED;
+  }
   if (batch == 0) return FMGAN_OK;
-  if (!in || !wt || !style || !out) return FMGAN_EINVAL;
+  if (!in || !wt || !style || (!out && !rgb)) return FMGAN_EINVAL;
+  if (rgb && (!rgb->wmod || !rgb->out)) return FMGAN_EINVAL;
   if (fuse_act && noise && noise_batch != 1 && noise_batch != batch) return FMGAN_EINVAL;
   MCParams p{};
+  if (rgb) {
+    p.rgb_wmod = rgb->wmod; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip; p.rgb_out = rgb->out; p.rgb_c = rgb->c;
+  }
   p.in = in; p.wt = wt; p.style = style; p.demod = demod; p.out = out;
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
   out_dims(mode, h, w, p.oh, p.ow);
@@ -897,6 +1075,7 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
   p.ksplit = pick_ksplit(mode, batch, cin, cout, h, w);
   const long long need = (long long)p.ksplit * batch * cout * p.oh * p.ow * (long long)sizeof(float);
   if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) p.ksplit = 1;
+  if (rgb) p.ksplit = 1;   // the RGB reduction needs the finished sums in one block
   p.ws = (float*)workspace;
   const int chunks = (cin + MC_KC - 1) / MC_KC;
   p.cin_per_split = ((chunks + p.ksplit - 1) / p.ksplit) * MC_KC;
@@ -923,6 +1102,44 @@ extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float
     st = fmgan_check_launch();
   }
   return st;
+}
+}  // namespace
+
+extern "C" int fmgan_modconv2d_f32(const float* in, const float* wt, const float* style, const float* demod,
+                                   float* out, int batch, int cin, int cout, int h, int w, int mode,
+                                   const float* noise, const float* noise_weight, const float* bias, int noise_batch,
+                                   int fuse_act, float alpha, float act_scale, long long out_plane_stride,
+                                   int out_row_stride, void* workspace, long long workspace_bytes, void* stream) {
+  return modconv2d_impl(in, wt, style, demod, out, batch, cin, cout, h, w, mode, noise, noise_weight, bias, noise_batch,
+                        fuse_act, alpha, act_scale, out_plane_stride, out_row_stride, workspace, workspace_bytes, stream,
+                        nullptr);
+}
+
+extern "C" int fmgan_torgb_weight_mod_f32(const float* weight, const float* style, float* wmod, int batch, int cout,
+                                          int rgb_channels, float scale, void* stream) {
+  if (batch < 0 || cout <= 0 || rgb_channels < 1 || rgb_channels > 3) return FMGAN_EINVAL;
+  if (batch == 0) return FMGAN_OK;
+  if (!weight || !style || !wmod) return FMGAN_EINVAL;
+  const int n = batch * 3 * cout;
+  hipLaunchKernelGGL(torgb_weight_mod_f32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, style, wmod,
+                     batch, cout, rgb_channels, scale);
+  return fmgan_check_launch();
+}
+
+extern "C" int fmgan_modconv2d_rgb_fusable(int batch, int cin, int cout, int h, int w) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+  return rgb_fusable(batch, cin, cout, h, w) ? 1 : 0;
+}
+
+extern "C" int fmgan_modconv2d_rgb_f32(const float* in, const float* wt, const float* style, const float* demod,
+                                       float* out, int batch, int cin, int cout, int h, int w,
+                                       const float* noise, const float* noise_weight, const float* bias,
+                                       int noise_batch, int fuse_act, float alpha, float act_scale,
+                                       const float* rgb_wmod, const float* rgb_bias,
+                                       const float* rgb_skip, float* rgb_out, int rgb_channels, void* stream) {
+  const RgbArgs rgb{rgb_wmod, rgb_bias, rgb_skip, rgb_out, rgb_channels};
+  return modconv2d_impl(in, wt, style, demod, out, batch, cin, cout, h, w, 0, noise, noise_weight, bias, noise_batch,
+                        fuse_act, alpha, act_scale, 0, 0, nullptr, 0, stream, &rgb);
 }
 
 extern "C" long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {

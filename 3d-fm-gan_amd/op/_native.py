@@ -45,9 +45,14 @@ def lib():
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
+    _sig(L.fmgan_modconv_wsq_f32, [vp] * 2 + [i] * 3 + [vp])
+    _sig(L.fmgan_modconv_demod_wsq_f32, [vp] * 3 + [i] * 3 + [f, f, vp])
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, i, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
+    _sig(L.fmgan_modconv2d_rgb_fusable, [i] * 5)
+    _sig(L.fmgan_torgb_weight_mod_f32, [vp] * 3 + [i] * 3 + [f, vp])
+    _sig(L.fmgan_modconv2d_rgb_f32, [vp] * 5 + [i] * 5 + [vp] * 3 + [i, i, f, f] + [vp] * 4 + [i, vp])
     _sig(L.fmgan_modconv_wgrad_workspace_bytes, [i] * 5, ll)
     _sig(L.fmgan_modconv_wgrad_f32, [vp] * 5 + [i] * 5 + [f, vp, ll, vp])
     _sig(L.fmgan_images_to_tensor, [vp, vp, i, i, i, f, f, vp])
@@ -229,15 +234,29 @@ def noise_bias_act(x, noise, noise_weight, bias, alpha, scale):
     return out
 
 
-def modconv_demod(weight, style, scale, eps=1e-8):
-    """weight [cout,cin,k,k] (or [1,cout,cin,k,k]) f32, style [B,cin] -> demod [B,cout]."""
+def modconv_demod(weight, style, scale, eps=1e-8, wsq=None):
+    """weight [cout,cin,k,k] (or [1,cout,cin,k,k]) f32, style [B,cin] -> demod [B,cout].
+    wsq: optional cached modconv_wsq(weight) — same bits, 1/k^2 of the reads."""
     cout, cin, kh, kw = weight.shape[-4:]
     style = style.contiguous()
     demod = torch.empty((style.shape[0], cout), dtype=torch.float32, device=style.device)
     with on_device(style) as stream:
-        check(lib().fmgan_modconv_demod_f32(ptr(weight), ptr(style), ptr(demod), style.shape[0], cout, cin, kh * kw,
-                                            float(scale), float(eps), stream), 'modconv_demod')
+        if wsq is not None:
+            check(lib().fmgan_modconv_demod_wsq_f32(ptr(wsq), ptr(style), ptr(demod), style.shape[0], cout, cin,
+                                                    float(scale), float(eps), stream), 'modconv_demod_wsq')
+        else:
+            check(lib().fmgan_modconv_demod_f32(ptr(weight), ptr(style), ptr(demod), style.shape[0], cout, cin,
+                                                kh * kw, float(scale), float(eps), stream), 'modconv_demod')
     return demod
+
+
+def modconv_wsq(weight):
+    """[.., cout,cin,k,k] -> per-(o,i) sum of squared taps [cout,cin] (input of modconv_demod(wsq=...))."""
+    cout, cin, kh, kw = weight.shape[-4:]
+    wsq = torch.empty((cout, cin), dtype=torch.float32, device=weight.device)
+    with on_device(weight) as stream:
+        check(lib().fmgan_modconv_wsq_f32(ptr(weight), ptr(wsq), cout, cin, kh * kw, stream), 'modconv_wsq')
+    return wsq
 
 
 def modconv_weight_prep(weight, scale, kind=0):
@@ -292,6 +311,37 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
                                         stream), 'modconv2d')
         _observer.end(tok)
     return out
+
+
+def modconv2d_rgb_fusable(batch, cin, cout, h, w):
+    return bool(lib().fmgan_modconv2d_rgb_fusable(int(batch), int(cin), int(cout), int(h), int(w)))
+
+
+def modconv2d_rgb(x, wt, style, demod, noise, noise_weight, bias, alpha, act_scale, rgb_weight, rgb_style, rgb_bias,
+                  rgb_skip, rgb_scale, keep_out=True):
+    """Plain 3x3 modulated conv + noise/bias/LeakyReLU with the following ToRGB (1x1 modulated conv + bias + skip) in
+    the same kernel.  Returns (activation or None, rgb [B,3,H,W]).  Shapes must satisfy modconv2d_rgb_fusable()."""
+    require_gpu(x, 'input')
+    x = x.contiguous()
+    style, rgb_style = style.contiguous(), rgb_style.contiguous()
+    b, cin, h, w = x.shape
+    cout = wt.shape[2]
+    rgb_c = rgb_weight.numel() // cout
+    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device) if keep_out else None
+    rgb = torch.empty((b, rgb_c, h, w), dtype=torch.float32, device=x.device)
+    nz = noise.contiguous() if noise is not None else None
+    sk = rgb_skip.contiguous() if rgb_skip is not None else None
+    wmod = torch.empty((b, 3, cout), dtype=torch.float32, device=x.device)
+    with on_device(x) as stream:
+        check(lib().fmgan_torgb_weight_mod_f32(ptr(rgb_weight), ptr(rgb_style), ptr(wmod), b, cout, rgb_c,
+                                               float(rgb_scale), stream), 'torgb_weight_mod')
+        tok = _observer.begin('modconv2d', (b, cin, cout, h, w, 0))
+        check(lib().fmgan_modconv2d_rgb_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), ptr(out), b, cin, cout, h, w,
+                                            ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
+                                            1, float(alpha), float(act_scale), ptr(wmod), ptr(rgb_bias), ptr(sk),
+                                            ptr(rgb), rgb_c, stream), 'modconv2d_rgb')
+        _observer.end(tok)
+    return out, rgb
 
 
 def modconv_wgrad(go, demod, x, style, scale):

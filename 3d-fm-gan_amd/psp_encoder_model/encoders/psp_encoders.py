@@ -17,6 +17,7 @@ from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
 
 from .helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
 from stylegan2 import EqualLinear
+from op import fused_leaky_relu
 from Util.streams import overlap_ok, run_on, side_streams
 
 # Inference: the style heads are independent of each other and each ends in a tail of tiny launches (conv at 16^2 ... 1^2
@@ -42,6 +43,18 @@ class GradualStyleBlock(Module):
         self.linear = EqualLinear(out_c, out_c, lr_mul=1)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32:
+            # conv, then bias + LeakyReLU(0.01) in ONE pass of the HIP fused_bias_act kernel (the same arithmetic as
+            # MIOpen's separate bias add followed by aten leaky_relu: (v + b) > 0 ? . : 0.01 * .  — bit-identical).
+            for conv, act in zip(self.convs[0::2], self.convs[1::2]):
+                y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
+                    n, c, h, w = y.shape                       # NHWC storage: channel is the fastest dimension
+                    y = fused_leaky_relu(y.permute(0, 2, 3, 1).reshape(-1, c), conv.bias, act.negative_slope, 1.0)
+                    x = y.view(n, h, w, c).permute(0, 3, 1, 2)
+                else:
+                    x = fused_leaky_relu(y, conv.bias, act.negative_slope, 1.0)
+            return self.linear(x.reshape(-1, self.out_c))
         return self.linear(self.convs(x).reshape(-1, self.out_c))
 
 

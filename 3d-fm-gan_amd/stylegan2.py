@@ -10,6 +10,7 @@ tests/golden/*_manifest.json), but the hot ops are hand-written gfx950 kernels r
 Host code stays PyTorch-ROCm.  There is no CPU path: CPU tensors raise RuntimeError in `op`.
 """
 import math
+import os
 import random
 
 import torch
@@ -174,6 +175,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
         self._wt = None  # (weight version, data_ptr, device) -> MFMA-layout copy of scale*weight
+        self._wsq = None  # same key -> per-(o,i) sum of squared taps (demodulation)
 
     def __repr__(self):
         return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
@@ -187,6 +189,15 @@ class ModulatedConv2d(nn.Module):
             with torch.no_grad():
                 self._wt = (key, _native.modconv_weight_prep(w.detach(), self.scale))
         return self._wt[1]
+
+    def mfma_wsq(self):
+        """Per-(o,i) sum of squared taps for the demodulation kernel, rebuilt only when the parameter changed."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), w.device)
+        if self._wsq is None or self._wsq[0] != key:
+            with torch.no_grad():
+                self._wsq = (key, _native.modconv_wsq(w.detach()))
+        return self._wsq[1]
 
     def styles(self, style):
         return self.modulation(style)
@@ -231,6 +242,9 @@ class ConstantInput(nn.Module):
         return self.input.repeat(input.shape[0], 1, 1, 1)
 
 
+FUSE_RGB = os.environ.get('FMGAN_NO_RGB_FUSE', '0') != '1'   # ToRGB in the preceding conv's epilogue (inference)
+
+
 class StyledConv(nn.Module):
     """ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU (stylegan2.py:332-376).
 
@@ -250,7 +264,7 @@ class StyledConv(nn.Module):
     def _fused(self, input, style, noise):
         conv, act = self.conv, self.activate
         s = conv.styles(style)
-        demod = _native.modconv_demod(conv.weight, s, conv.scale, conv.eps) if conv.demodulate else None
+        demod = _native.modconv_demod(conv.weight, s, conv.scale, conv.eps, conv.mfma_wsq()) if conv.demodulate else None
         b, _, h, w = input.shape
         oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
         if noise is None:
@@ -275,6 +289,25 @@ class StyledConv(nn.Module):
                                     noise_weight=self.noise.weight, bias=act.bias, fuse_act=True,
                                     alpha=act.negative_slope, act_scale=act.scale)
         return out, s
+
+    def rgb_fusable(self, x_shape, x):
+        """Can this (plain) StyledConv take the following ToRGB into its epilogue for an input of this shape?"""
+        conv = self.conv
+        if conv.upsample or conv.downsample or torch.is_grad_enabled() or not modconv.hip_conv_ok(x, conv.weight):
+            return False
+        b, _, h, w = x_shape
+        return _native.modconv2d_rgb_fusable(b, conv.in_channel, conv.out_channel, h, w)
+
+    def fused_with_rgb(self, input, style, noise, to_rgb, rgb_latent, skip_up, keep_out):
+        """StyledConv + ToRGB in one kernel (inference): returns (activation or None, rgb)."""
+        conv, act = self.conv, self.activate
+        s = conv.styles(style)
+        demod = _native.modconv_demod(conv.weight, s, conv.scale, conv.eps, conv.mfma_wsq()) if conv.demodulate else None
+        if noise is None:
+            noise = input.new_empty(input.shape[0], 1, input.shape[2], input.shape[3]).normal_()
+        return _native.modconv2d_rgb(input, conv.mfma_weight(), s, demod, noise, self.noise.weight, act.bias,
+                                     act.negative_slope, act.scale, to_rgb.conv.weight, to_rgb.conv.styles(rgb_latent),
+                                     to_rgb.bias, skip_up, to_rgb.conv.scale, keep_out)
 
     def forward(self, input, style, return_style_scalars=False, noise=None):
         if (not torch.is_grad_enabled()) and modconv.hip_conv_ok(input, self.conv.weight) and not self.conv.downsample:
@@ -428,6 +461,28 @@ class Generator(nn.Module):
         rgbs = [skip]
         for blk, to_rgb in enumerate(self.to_rgbs):
             i = 1 + 2 * blk
+            conv_b = self.convs[2 * blk + 1]
+            b_, _, h_, w_ = out.shape
+            # Inference, last resolution: its ToRGB cannot hide beside later convs (there are none) and is the only
+            # consumer of conv_b's activation, so it rides in conv_b's epilogue and the [B,C,size,size] activation is
+            # never written or re-read (2.1 GB of HBM traffic at 1024^2, B=8).  Lower resolutions keep the separate
+            # ToRGB kernel: it overlaps the next resolution's MFMA-bound convs on the side stream (measured: fusing
+            # those too is time-neutral on the conv and puts the RGB reduction on the critical path).
+            last = blk + 1 == len(self.to_rgbs)
+            if (FUSE_RGB and last and not return_style_scalars and not return_rgb_list
+                    and conv_b.rgb_fusable((b_, 0, 2 * h_, 2 * w_), out)):
+                if overlap:
+                    join_up, skip_up = run_on(side, to_rgb.upsample, skip)
+                    joins.append(join_up)
+                else:
+                    skip_up = to_rgb.upsample(skip)
+                out = self.convs[2 * blk](out, latent[:, i], noise=noise[i])
+                if overlap:
+                    join_up()
+                out, skip = conv_b.fused_with_rgb(out, latent[:, i + 1], noise[i + 1], to_rgb, latent[:, i + 2], skip_up,
+                                                  keep_out=False)
+                rgbs.append(skip)
+                continue
             out = run(self.convs[2 * blk], out, latent[:, i], noise=noise[i])
             out = run(self.convs[2 * blk + 1], out, latent[:, i + 1], noise=noise[i + 1])
             if return_style_scalars and i + 3 == latent.shape[1]:   # style scalars of the last ToRGB only (:660-662)
@@ -437,10 +492,10 @@ class Generator(nn.Module):
             rgbs.append(skip)
         for join in joins[-1:]:
             join()                      # the side stream is in order: joining its last launch joins all of them
+        image = skip
         for r in rgbs[:-1]:
             if overlap:
-                r.record_stream(torch.cuda.current_stream(out.device))
-        image = skip
+                r.record_stream(torch.cuda.current_stream(image.device))
 
         if PPL_regularize:
             # path-length regulariser evaluated inside forward so it shards with the batch (stylegan2.py:683-688)

@@ -151,6 +151,17 @@ int fmgan_modconv_demod_f32(const float *weight, const float *style, float *demo
                             float scale, float eps, void *stream);
 
 /*
+ * The same coefficients in two steps, for weights that change rarely (inference, or once per optimiser step):
+ *   fmgan_modconv_wsq_f32:        wsq[o,i] = sum_k weight[o,i,k]^2          [cout, cin] f32, cached by the caller
+ *   fmgan_modconv_demod_wsq_f32:  demod[b,o] = rsqrt(scale^2 * sum_i wsq[o,i] * style[b,i]^2 + eps)
+ * Same fma chains in the same order as fmgan_modconv_demod_f32: bit-identical results; the per-forward kernel reads
+ * cout*cin floats instead of cout*cin*ktaps.
+ */
+int fmgan_modconv_wsq_f32(const float *weight, float *wsq, int cout, int cin, int ktaps, void *stream);
+int fmgan_modconv_demod_wsq_f32(const float *wsq, const float *style, float *demod,
+                                int batch, int cout, int cin, float scale, float eps, void *stream);
+
+/*
  * Weight layouts for the MFMA contraction (last index contiguous, so a 32-lane MFMA A-operand read is one LDS bank
  * row and staging is coalesced).  weight [cout, cin, ktaps] f32; wt pre-allocated, cout*cin*ktaps floats:
  *   kind 0  wt[i][tap][o] = scale * weight[o][i][tap]            forward (modes 0, 1, and the downsample branch, mode 2)
@@ -194,6 +205,33 @@ int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
                         int noise_batch, int fuse_act, float alpha, float act_scale,
                         long long out_plane_stride, int out_row_stride,
                         void *workspace, long long workspace_bytes, void *stream);
+
+/*
+ * Plain (mode 0) modulated conv with the FOLLOWING ToRGB layer folded into its epilogue.  In the reference these are
+ * two modules and three HBM passes over the activation (StyledConv conv2 -> ToRGB, stylegan2.py:646-651 calling
+ * :360-376 and :393-404).  When one block holds every output channel of its pixels (cout <= the tile's channel
+ * extent and every tile lies in one sample: fmgan_modconv2d_rgb_fusable() == 1; the launch runs without split-K), the 1x1 modulated conv to <= 3 channels is a reduction
+ * over the accumulator rows:
+ *   act[b,o,p]  = lrelu(demod*conv + noise_weight*noise + bias) * act_scale          (as fmgan_modconv2d_f32)
+ *   rgb[b,c,p]  = sum_o act[b,o,p] * wmod[b,c,o] + rgb_bias[c] + rgb_skip[b,c,p]
+ *   wmod[b,c,o] = rgb_scale * rgb_weight[c,o] * rgb_style[b,o]   ([batch, 3, cout], rows >= rgb_channels zero) is
+ *   built once per forward by fmgan_torgb_weight_mod_f32 from the [1,3,cout,1,1] ToRGB parameter and its style;
+ *   rgb_bias [rgb_channels] or NULL, rgb_skip [batch, rgb_channels, h, w] (the already upsampled skip) or NULL,
+ *   rgb_out like rgb_skip.
+ * out may be NULL: the activation is then never written (last layer of the synthesis network — ToRGB is its only
+ * consumer).  Summation order over o is fixed (rows of a lane, lane halves, then waves): run-to-run bit-identical.
+ * Returns FMGAN_EUNSUPPORTED when the shape is not fusable; the caller then runs fmgan_modconv2d_f32 + fmgan_torgb_f32.
+ */
+int fmgan_torgb_weight_mod_f32(const float *rgb_weight, const float *rgb_style, float *wmod,
+                               int batch, int cout, int rgb_channels, float rgb_scale, void *stream);
+int fmgan_modconv2d_rgb_fusable(int batch, int cin, int cout, int h, int w);
+int fmgan_modconv2d_rgb_f32(const float *in, const float *wt, const float *style,
+                            const float *demod, float *out,
+                            int batch, int cin, int cout, int h, int w,
+                            const float *noise, const float *noise_weight, const float *bias,
+                            int noise_batch, int fuse_act, float alpha, float act_scale,
+                            const float *rgb_wmod, const float *rgb_bias,
+                            const float *rgb_skip, float *rgb_out, int rgb_channels, void *stream);
 
 /*
  * Weight gradient of the plain (mode 0) modulated conv on the MFMA units:

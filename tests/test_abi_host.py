@@ -178,3 +178,26 @@ def test_network_shape_helpers():
     assert network_util.Get_Network_Shape(g.state_dict()) == shape
     g2 = network_util.Build_Generator_From_Dict(g.state_dict(), size=64, n_mlp=2)
     assert [tuple(v.shape) for v in g2.state_dict().values()] == [tuple(v.shape) for v in g.state_dict().values()]
+
+
+def test_training_losses_on_cpu_tensors():
+    """Util/training_util.py mirrors the reference's GAN losses (training_util.py:24-58): closed forms on CPU tensors."""
+    import math
+    from Util import training_util as TU
+    real, fake = torch.tensor([[0.5], [-1.0]]), torch.tensor([[2.0], [0.0]])
+    sp = lambda v: math.log1p(math.exp(v))
+    assert abs(TU.d_logistic_loss(real, fake).item() - ((sp(-0.5) + sp(1.0)) / 2 + (sp(2.0) + sp(0.0)) / 2)) < 1e-6
+    assert abs(TU.g_nonsaturating_loss(fake).item() - (sp(-2.0) + sp(0.0)) / 2) < 1e-6
+    x = torch.tensor([[1.0, 2.0], [3.0, 4.0]], requires_grad=True)
+    pred = (x ** 2).sum(1, keepdim=True)                      # d/dx = 2x  ->  R1 = mean_b sum 4 x^2
+    r1 = TU.d_r1_loss(pred, x)
+    assert abs(r1.item() - (4 * (1 + 4) + 4 * (9 + 16)) / 2) < 1e-5
+    r1.backward()                                             # second order: d R1 / dx = 8x / batch
+    assert torch.allclose(x.grad, 4 * x.detach())
+    lat = torch.ones(2, 3, 4, requires_grad=True)
+    img = (lat.sum((1, 2))[:, None, None, None] * torch.ones(2, 1, 2, 2))
+    pen, mean, pl = TU.g_path_regularize(img, lat, torch.tensor(0.0), probe=torch.ones_like(img))
+    # probe / sqrt(4) = 0.5 per pixel, 4 pixels -> d/dlat = 2 everywhere; length = sqrt(mean_over_latents(sum_512 4))
+    assert torch.allclose(pl, torch.full((2,), math.sqrt(4 * 4))) and abs(mean.item() - 0.04) < 1e-6
+    assert abs(pen.item() - (4 - 0.04) ** 2) < 1e-4
+    assert abs(TU.L1_Loss(torch.zeros(2, 3), torch.full((2, 3), -2.0)).item() - 2.0) < 1e-7

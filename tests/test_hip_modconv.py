@@ -77,6 +77,71 @@ def test_modconv_kernel_vs_c_oracle(cfg, demod):
     np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
 
 
+@pytest.mark.parametrize('cfg', [
+    # (batch, cin, cout, h, w, keep_out): cout <= 32 -> 32x512 tile, <= 64 -> 64x256, <= 128 -> 128x128 (two channel waves)
+    (2, 32, 32, 64, 64, True), (1, 24, 20, 70, 66, True), (2, 16, 32, 128, 128, False),
+    (2, 64, 64, 48, 48, True), (1, 40, 50, 75, 61, False),
+    (2, 128, 128, 40, 40, True), (1, 72, 100, 49, 57, False), (3, 16, 128, 32, 32, True),
+])
+def test_conv_with_torgb_in_epilogue_vs_c_oracle(cfg):
+    """fmgan_modconv2d_rgb_f32: StyledConv (conv + noise + bias + lrelu) and the following ToRGB (+ bias + skip) in one
+    kernel vs the two C-oracle steps; also against this repo's own two-kernel path."""
+    from op import _native
+    from oracle import c_oracle
+    b, cin, cout, h, w, keep = cfg
+    assert _native.modconv2d_rgb_fusable(b, cin, cout, h, w)
+    x = synth.tensor(f'rgbf/{cfg}/x', (b, cin, h, w))
+    wgt = synth.tensor(f'rgbf/{cfg}/w', (cout, cin, 3, 3))
+    s = synth.tensor(f'rgbf/{cfg}/s', (b, cin), shift=1.0, scale=0.5)
+    noise = synth.tensor(f'rgbf/{cfg}/n', (b, 1, h, w))
+    nw = torch.tensor([0.3])
+    bias = synth.tensor(f'rgbf/{cfg}/b', (cout,))
+    rw = synth.tensor(f'rgbf/{cfg}/rw', (3, cout))
+    rs = synth.tensor(f'rgbf/{cfg}/rs', (b, cout), shift=1.0, scale=0.5)
+    rb = synth.tensor(f'rgbf/{cfg}/rb', (3,))
+    skip = synth.tensor(f'rgbf/{cfg}/k', (b, 3, h, w))
+    scale, rscale = 1.0 / np.sqrt(cin * 9), 1.0 / np.sqrt(cout)
+    conv = c_oracle.modulated_conv2d(x.numpy(), wgt.numpy(), s.numpy(), mode=0, demodulate=True)
+    pre = conv + np.float32(0.3) * noise.numpy() + bias.numpy()[None, :, None, None]
+    act = (np.where(pre > 0, pre, pre * np.float32(0.2)) * np.float32(2 ** 0.5)).astype(np.float32)
+    rgb_ref = c_oracle.to_rgb(act, rw.numpy(), rs.numpy(), rb.numpy(), skip.numpy())
+    d = dev()
+    xd, wd, sd = x.to(d), wgt.to(d), s.to(d)
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale)
+    out, rgb = _native.modconv2d_rgb(xd, wt, sd, dm, noise.to(d), nw.to(d), bias.to(d), 0.2, 2 ** 0.5, rw.to(d), rs.to(d),
+                                     rb.to(d), skip.to(d), rscale, keep_out=keep)
+    np.testing.assert_allclose(rgb.cpu().numpy(), rgb_ref, **_tol(rgb_ref))
+    two = _native.modconv2d(xd, wt, sd, dm, 0, noise=noise.to(d), noise_weight=nw.to(d), bias=bias.to(d), fuse_act=True)
+    if keep:
+        # the activation is the same conv (the two-kernel path may sum in split-K order: compare within tolerance)
+        np.testing.assert_allclose(out.cpu().numpy(), two.cpu().numpy(), **_tol(act))
+        np.testing.assert_allclose(out.cpu().numpy(), act, **_tol(act))
+    else:
+        assert out is None
+    rgb2 = _native.torgb(two, rw.to(d), rs.to(d), rb.to(d), skip.to(d), rscale)
+    np.testing.assert_allclose(rgb.cpu().numpy(), rgb2.cpu().numpy(), **_tol(rgb_ref))
+    # no skip / no bias
+    _, rgb3 = _native.modconv2d_rgb(xd, wt, sd, dm, noise.to(d), nw.to(d), bias.to(d), 0.2, 2 ** 0.5, rw.to(d), rs.to(d),
+                                    None, None, rscale, keep_out=False)
+    ref3 = c_oracle.to_rgb(act, rw.numpy(), rs.numpy(), None, None)
+    np.testing.assert_allclose(rgb3.cpu().numpy(), ref3, **_tol(ref3))
+
+
+def test_rgb_fusable_is_host_logic_and_unsupported_shapes_are_refused():
+    from op import _native
+    assert _native.modconv2d_rgb_fusable(8, 32, 32, 1024, 1024) and _native.modconv2d_rgb_fusable(8, 64, 64, 512, 512)
+    assert _native.modconv2d_rgb_fusable(8, 128, 128, 256, 256)
+    assert not _native.modconv2d_rgb_fusable(8, 256, 256, 128, 128)      # two output-channel tiles
+    assert not _native.modconv2d_rgb_fusable(1, 512, 512, 4, 4)          # tiny layer: small tiles, 16 channel tiles
+    x = torch.zeros(1, 256, 128, 128, device=dev())
+    wt = torch.zeros(256, 9, 256, device=dev())
+    s = torch.ones(1, 256, device=dev())
+    with pytest.raises(RuntimeError):
+        _native.modconv2d_rgb(x, wt, s, None, None, None, None, 0.2, 1.0, torch.zeros(3, 256, device=dev()), s, None,
+                              None, 1.0)
+
+
 @pytest.mark.parametrize('c', cases.STYLEDCONV_CASES, ids=lambda c: c['name'])
 def test_styled_conv_golden_fused_and_unfused(c, golden):
     import stylegan2
@@ -134,6 +199,24 @@ def test_weight_prep_layouts():
     np.testing.assert_array_equal(k0, wn.transpose(1, 2, 0))
     np.testing.assert_array_equal(k1, wn[:, :, ::-1].transpose(0, 2, 1))
     np.testing.assert_array_equal(k2, wn.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize('shape', [(20, 12, 3), (64, 520, 3), (3, 32, 1), (130, 600, 3)])
+def test_demod_from_cached_wsq_is_bit_identical(shape):
+    """fmgan_modconv_wsq_f32 + fmgan_modconv_demod_wsq_f32 (what inference uses, wsq cached with the weight) must give
+    the bits of fmgan_modconv_demod_f32, and both match the float64 closed form."""
+    from op import _native
+    cout, cin, k = shape
+    w = synth.tensor(f'wsq/{cout}x{cin}/w', (cout, cin, k, k))
+    s = synth.tensor(f'wsq/{cout}x{cin}/s', (3, cin))
+    scale = 1.0 / np.sqrt(cin * k * k)
+    wd, sdv = w.to(dev()), s.to(dev())
+    direct = _native.modconv_demod(wd, sdv, scale)
+    wsq = _native.modconv_wsq(wd)
+    cached = _native.modconv_demod(wd, sdv, scale, wsq=wsq)
+    assert torch.equal(direct, cached)
+    ref = 1.0 / np.sqrt((scale * scale) * (s.double().numpy() ** 2) @ (w.double().numpy() ** 2).sum((2, 3)).T + 1e-8)
+    np.testing.assert_allclose(cached.cpu().numpy(), ref, rtol=2e-6)
 
 
 @pytest.mark.parametrize('cfg', [(2, 6, 10, 5, False, True), (2, 6, 10, 5, True, True), (3, 20, 136, 8, False, True),

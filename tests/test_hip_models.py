@@ -163,9 +163,12 @@ def test_generator_gradients_and_path_length_vs_oracle():
     close(gld, glo, 1e-3)
     close(gtd, gto, 1e-3)
     close(gwd, gwo, 1e-3)
-    gpl_d, = torch.autograd.grad((img_d * probe.float().to(dev())).sum(), ld, create_graph=True)
-    pl_d = torch.sqrt(gpl_d.pow(2).sum(2).mean(1))
-    gpl2_d, = torch.autograd.grad(pl_d.sum(), ld)
+    from Util.training_util import g_path_regularize
+    pen_d, mean_d, pl_d = g_path_regularize(img_d, ld, 0.5, probe=synth.tensor('gg/probe', (2, 3, 32, 32)).to(dev()))
+    gpl2_d, = torch.autograd.grad(pl_d.sum(), ld, retain_graph=True)
+    mean_o = 0.5 + 0.01 * (pl_o.mean() - 0.5)
+    np.testing.assert_allclose(mean_d.item(), mean_o.item(), rtol=1e-3)
+    np.testing.assert_allclose(pen_d.item(), (pl_o - mean_o).pow(2).mean().item(), rtol=5e-3)
     close(pl_d, pl_o, 1e-3)
     close(gpl2_d, gpl2_o, 5e-3)
     # and the PPL_regularize=True return signature
@@ -189,11 +192,15 @@ def test_discriminator_r1_penalty_vs_oracle():
     gxo, = torch.autograd.grad(yo.sum(), xo, create_graph=True)
     r1_o = gxo.pow(2).reshape(4, -1).sum(1).mean()
     gw_o, = torch.autograd.grad(r1_o, sd64[wkey])
+    from Util.training_util import d_r1_loss, d_logistic_loss, g_nonsaturating_loss
     xd = x.to(dev()).requires_grad_(True)
     yd = D(xd)
-    gxd, = torch.autograd.grad(yd.sum(), xd, create_graph=True)
-    r1_d = gxd.pow(2).reshape(4, -1).sum(1).mean()
+    r1_d = d_r1_loss(yd, xd)
     gw_d, = torch.autograd.grad(r1_d, dict(D.named_parameters())[wkey])
+    sp = torch.nn.functional.softplus
+    np.testing.assert_allclose(d_logistic_loss(yd[:2], yd[2:]).item(),
+                               (sp(-yo[:2]).mean() + sp(yo[2:]).mean()).item(), rtol=1e-4)
+    np.testing.assert_allclose(g_nonsaturating_loss(yd).item(), sp(-yo).mean().item(), rtol=1e-4)
     np.testing.assert_allclose(yd.detach().cpu().numpy(), yo.detach().numpy(), atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(r1_d.item(), r1_o.item(), rtol=1e-3)
     ref = gw_o.numpy()

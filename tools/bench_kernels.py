@@ -100,6 +100,33 @@ def main():
             ms, _ = timeit(lambda: _native.torgb(x, w, s, bias, skip, 1.0))
             gb = 4.0 * (x.numel() + 2 * skip.numel()) / 1e9
             print(f'  res {r:5d} C {c:4d}: {ms * 1e3:9.1f} us {gb / ms * 1e3:8.1f} GB/s')
+    if 'rgbfuse' in what:
+        print(f'== StyledConv (plain) + ToRGB: two kernels vs ToRGB in the conv epilogue, B={B}')
+        for r in res_list:
+            c = channels(r)
+            if not _native.modconv2d_rgb_fusable(B, c, c, r, r):
+                continue
+            x = torch.randn(B, c, r, r, device=d)
+            wgt = torch.randn(c, c, 3, 3, device=d)
+            s = torch.randn(B, c, device=d)
+            wt = _native.modconv_weight_prep(wgt, 1.0 / (c * 9) ** 0.5)
+            dm = _native.modconv_demod(wgt, s, 1.0 / (c * 9) ** 0.5)
+            noise = torch.randn(B, 1, r, r, device=d)
+            nw = torch.zeros(1, device=d)
+            bias = torch.zeros(c, device=d)
+            rw = torch.randn(3, c, device=d)
+            rb = torch.zeros(3, device=d)
+            skip = torch.randn(B, 3, r, r, device=d)
+
+            def two():
+                y = _native.modconv2d(x, wt, s, dm, 0, noise=noise, noise_weight=nw, bias=bias, fuse_act=True)
+                return _native.torgb(y, rw, s, rb, skip, 1.0)
+            t_conv, _ = timeit(lambda: _native.modconv2d(x, wt, s, dm, 0, noise=noise, noise_weight=nw, bias=bias, fuse_act=True))
+            t_two, _ = timeit(two)
+            t_keep, _ = timeit(lambda: _native.modconv2d_rgb(x, wt, s, dm, noise, nw, bias, 0.2, 2 ** 0.5, rw, s, rb, skip, 1.0, True))
+            t_drop, _ = timeit(lambda: _native.modconv2d_rgb(x, wt, s, dm, noise, nw, bias, 0.2, 2 ** 0.5, rw, s, rb, skip, 1.0, False))
+            print(f'  res {r:5d} C {c:4d}: conv {t_conv * 1e3:8.1f} us | conv+torgb {t_two * 1e3:8.1f} us | fused {t_keep * 1e3:8.1f} us | '
+                  f'fused, activation not stored {t_drop * 1e3:8.1f} us')
 
 
 if __name__ == '__main__':
