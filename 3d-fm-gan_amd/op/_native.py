@@ -56,6 +56,10 @@ def lib():
     _sig(L.fmgan_modconv_wgrad_workspace_bytes, [i] * 5, ll)
     _sig(L.fmgan_modconv_wgrad_f32, [vp] * 5 + [i] * 5 + [f, vp, ll, vp])
     _sig(L.fmgan_images_to_tensor, [vp, vp, i, i, i, f, f, vp])
+    _sig(L.fmgan_resize_output_size, [i, i, i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)])
+    _sig(L.fmgan_resize_plan_ints, [i] * 4, ll)
+    _sig(L.fmgan_resize_plan, [i] * 4 + [vp, ll])
+    _sig(L.fmgan_resize_bilinear_u8, [vp] * 4 + [i] * 5 + [f, f, vp])
     _sig(L.fmgan_tensor_to_images, [vp, vp, i, i, i, f, f, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
     if L.fmgan_abi_version() != 1:
@@ -390,6 +394,52 @@ def images_to_tensor(images, mean=0.5, std=0.5):
     out = torch.empty((b, 3, h, w), dtype=torch.float32, device=x.device)
     with on_device(x) as stream:
         check(lib().fmgan_images_to_tensor(ptr(x), ptr(out), b, h, w, float(mean), float(std), stream), 'images_to_tensor')
+    return out
+
+
+def resize_output_size(h, w, size):
+    """torchvision Resize(int) rule: (out_h, out_w) for an [h, w] image (host logic, no GPU needed)."""
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    check(lib().fmgan_resize_output_size(int(h), int(w), int(size), ctypes.byref(oh), ctypes.byref(ow)), 'resize_output_size')
+    return oh.value, ow.value
+
+
+def resize_plan(in_h, in_w, out_h, out_w):
+    """Pillow's bilinear coefficient tables for this size pair as a CPU int32 tensor (host logic, no GPU needed)."""
+    n = lib().fmgan_resize_plan_ints(int(in_h), int(in_w), int(out_h), int(out_w))
+    if n <= 0:
+        raise RuntimeError('resize_plan: invalid sizes')
+    plan = torch.empty(n, dtype=torch.int32)
+    check(lib().fmgan_resize_plan(int(in_h), int(in_w), int(out_h), int(out_w), plan.data_ptr(), n), 'resize_plan')
+    return plan
+
+
+_PLANS = {}
+
+
+def resize_images(images, out_h, out_w, to_tensor=False, mean=0.5, std=0.5):
+    """uint8 [B,H,W,3] (GPU) -> PIL-exact bilinear resize.  to_tensor=False: uint8 [B,out_h,out_w,3];
+    to_tensor=True: float32 [B,3,out_h,out_w] = ((v/255) - mean)/std (Resize + ToTensor + Normalize in one pass)."""
+    require_gpu(images, 'images')
+    if images.dtype != torch.uint8 or images.ndim != 4 or images.shape[-1] != 3:
+        raise RuntimeError('resize_images: expected a uint8 [B,H,W,3] tensor')
+    x = images.contiguous()
+    b, h, w, _ = x.shape
+    key = (x.device, h, w, out_h, out_w)
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _PLANS[key] = resize_plan(h, w, out_h, out_w).to(x.device)
+    if to_tensor:
+        out = torch.empty((b, 3, out_h, out_w), dtype=torch.float32, device=x.device)
+        o8, o32 = None, out
+    else:
+        out = torch.empty((b, out_h, out_w, 3), dtype=torch.uint8, device=x.device)
+        o8, o32 = out, None
+    with on_device(x) as stream:
+        tok = _observer.begin('resize', (b, h, w, out_h, out_w))
+        check(lib().fmgan_resize_bilinear_u8(ptr(x), ptr(plan), ptr(o8), ptr(o32), b, h, w, out_h, out_w, float(mean),
+                                             float(std), stream), 'resize_bilinear_u8')
+        _observer.end(tok)
     return out
 
 

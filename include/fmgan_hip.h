@@ -25,6 +25,7 @@
  *                             (F.conv2d / F.conv_transpose2d with groups=batch)
  *   fmgan_torgb            <- ToRGB.forward            stylegan2.py:389-404
  *   fmgan_images_to_tensor <- transforms.ToTensor()+Normalize   train_3_encoder.py:233-239
+ *   fmgan_resize_*         <- transforms.Resize(size) (PIL BILINEAR) train_3_encoder.py:235
  *   fmgan_tensor_to_images <- tensor2im                 Evaluation/visual_eval.py:24-38
  */
 #ifndef FMGAN_HIP_H
@@ -259,11 +260,32 @@ int fmgan_torgb_f32(const float *in, const float *weight, const float *style,
 /*
  * The steps either side of the path, 3-channel images:
  *   fmgan_images_to_tensor: in uint8 [batch,h,w,3] -> out f32 [batch,3,h,w] = ((in/255) - mean) / std
- *       == transforms.ToTensor() + Normalize(mean, std) (train_3_encoder.py:233-239; Resize(size) is the identity
- *       for the 256^2 datasets of the reference and is not provided)
+ *       == transforms.ToTensor() + Normalize(mean, std) (train_3_encoder.py:233-239; Resize: fmgan_resize_* below)
  *   fmgan_tensor_to_images: in f32 [batch,3,h,w] -> out uint8 [batch,h,w,3] = (uint8)((clip(in,-1,1) + cent) * factor)
  *       == tensor2im (Evaluation/visual_eval.py:24-38), for every image of the batch.
  */
+/*
+ * transforms.Resize(size) of the same pipeline (train_3_encoder.py:233-239) = PIL.Image.resize(BILINEAR), whose
+ * arithmetic is Pillow's ImagingResample (third-party, pinned pillow=8.2.0: src/libImaging/Resample.c): per-axis tap
+ * windows of the triangle filter stretched by max(scale,1), weights in 22-bit fixed point, a horizontal then a
+ * vertical integer pass with a uint8 rounding in between.  Bit-exact with Pillow.
+ *   fmgan_resize_output_size : torchvision's Resize(int) rule (shorter edge -> size, longer int(size*long/short),
+ *                              unchanged if the shorter edge already equals size).
+ *   fmgan_resize_plan_ints / fmgan_resize_plan : HOST functions; fill a caller-owned host buffer with the coefficient
+ *       tables for (in_h,in_w)->(out_h,out_w): header[8] = {ksize_x, ksize_y, in_h, in_w, out_h, out_w, max input
+ *       rows per 8-row output tile, 8}, then bounds_x[2*out_w], coeff_x[out_w*ksize_x], bounds_y[2*out_h],
+ *       coeff_y[out_h*ksize_y].  The caller copies it to the device once per size pair.
+ *   fmgan_resize_bilinear_u8 : in uint8 [batch,in_h,in_w,3] -> out_u8 uint8 [batch,out_h,out_w,3] (what PIL returns)
+ *       and/or out_f32 f32 [batch,3,out_h,out_w] = ((v/255) - mean) / std (Resize + ToTensor + Normalize in one pass);
+ *       either output may be NULL.  `plan` is the DEVICE copy of the table for exactly these sizes.
+ */
+int fmgan_resize_output_size(int h, int w, int size, int *out_h, int *out_w);
+long long fmgan_resize_plan_ints(int in_h, int in_w, int out_h, int out_w);
+int fmgan_resize_plan(int in_h, int in_w, int out_h, int out_w, int *plan, long long plan_ints);
+int fmgan_resize_bilinear_u8(const unsigned char *in, const int *plan, unsigned char *out_u8, float *out_f32,
+                             int batch, int in_h, int in_w, int out_h, int out_w,
+                             float mean, float stdv, void *stream);
+
 int fmgan_images_to_tensor(const unsigned char *in, float *out, int batch, int h, int w,
                            float mean, float stdv, void *stream);
 int fmgan_tensor_to_images(const float *in, unsigned char *out, int batch, int h, int w,

@@ -122,3 +122,26 @@ def to_rgb(x, weight, style, bias=None, skip=None):
     if st != 0:
         raise RuntimeError(f'oracle_to_rgb status {st}')
     return out
+
+
+def resize_bilinear_u8(img, out_h, out_w):
+    """img [H,W,C] uint8 -> [out_h,out_w,C] uint8, Pillow's Image.resize(BILINEAR) arithmetic."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, c = img.shape
+    out = np.empty((out_h, out_w, c), dtype=np.uint8)
+    fn = lib().oracle_resize_bilinear_u8
+    fn.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 5
+    st = fn(_p(img), _p(out), h, w, c, out_h, out_w)
+    if st != 0:
+        raise RuntimeError(f'oracle_resize_bilinear_u8 status {st}')
+    return out
+
+
+def resized_output_size(h, w, size):
+    """torchvision.transforms.Resize(int) on a PIL image: the shorter edge becomes `size`, the longer
+    int(size * long / short); unchanged when the shorter edge already equals size."""
+    short, long_ = (w, h) if w <= h else (h, w)
+    if short == size:
+        return h, w
+    new_short, new_long = size, int(size * long_ / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)

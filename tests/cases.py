@@ -145,3 +145,12 @@ def tensor2im_input(c):
     x = synth.tensor(c['name'] + '/x', c['shape'], scale=0.8)
     x.view(-1)[:8] = torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, 0.999999, -0.999999, 0.00392])
     return x
+
+# (name, in_h, in_w, out_h, out_w): PIL.Image.resize(BILINEAR) cases — shrink (antialiased), enlarge, identity axes,
+# odd sizes, extreme aspect, 1-pixel outputs
+RESIZE_CASES = [
+    ('rz_quarter', 64, 64, 16, 16), ('rz_odd_down', 37, 53, 11, 20), ('rz_up', 17, 5, 40, 40),
+    ('rz_mixed', 33, 77, 33, 20), ('rz_wide', 50, 50, 7, 91), ('rz_third', 99, 66, 33, 22),
+    ('rz_one', 5, 5, 1, 1), ('rz_tiny_up', 2, 3, 9, 8), ('rz_512_smooth', 128, 128, 32, 32),
+    ('rz_frac_smooth', 100, 60, 64, 38),
+]

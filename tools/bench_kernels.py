@@ -127,6 +127,21 @@ def main():
             t_drop, _ = timeit(lambda: _native.modconv2d_rgb(x, wt, s, dm, noise, nw, bias, 0.2, 2 ** 0.5, rw, s, rb, skip, 1.0, False))
             print(f'  res {r:5d} C {c:4d}: conv {t_conv * 1e3:8.1f} us | conv+torgb {t_two * 1e3:8.1f} us | fused {t_keep * 1e3:8.1f} us | '
                   f'fused, activation not stored {t_drop * 1e3:8.1f} us')
+    if 'io' in what:
+        print('== input/output pipeline (uint8 images <-> tensors)')
+        for b, hin, hout in ((32, 1024, 256), (32, 512, 256), (8, 1024, 1024), (32, 256, 256)):
+            img = torch.randint(0, 256, (b, hin, hin, 3), dtype=torch.uint8, device=d)
+            if hin != hout:
+                ms, _ = timeit(lambda: _native.resize_images(img, hout, hout, to_tensor=True))
+                gb = (img.numel() + 4.0 * b * 3 * hout * hout) / 1e9
+                print(f'  resize+ToTensor+Normalize B={b} {hin}^2 -> {hout}^2: {ms * 1e3:8.1f} us {gb / ms * 1e3:8.1f} GB/s')
+            else:
+                ms, _ = timeit(lambda: _native.images_to_tensor(img))
+                gb = (img.numel() * 5.0) / 1e9
+                print(f'  ToTensor+Normalize        B={b} {hin}^2          : {ms * 1e3:8.1f} us {gb / ms * 1e3:8.1f} GB/s')
+                t = _native.images_to_tensor(img)
+                ms, _ = timeit(lambda: _native.tensor_to_images(t))
+                print(f'  tensor2im                 B={b} {hin}^2          : {ms * 1e3:8.1f} us {gb / ms * 1e3:8.1f} GB/s')
 
 
 if __name__ == '__main__':
