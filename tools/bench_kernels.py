@@ -127,6 +127,23 @@ def main():
             t_drop, _ = timeit(lambda: _native.modconv2d_rgb(x, wt, s, dm, noise, nw, bias, 0.2, 2 ** 0.5, rw, s, rb, skip, 1.0, False))
             print(f'  res {r:5d} C {c:4d}: conv {t_conv * 1e3:8.1f} us | conv+torgb {t_two * 1e3:8.1f} us | fused {t_keep * 1e3:8.1f} us | '
                   f'fused, activation not stored {t_drop * 1e3:8.1f} us')
+    if 'blurfuse' in what:
+        print(f'== upsampling StyledConv tail: blur + noise + bias + lrelu in one pass (aligned-row strided input), B={B}')
+        for r in res_list:
+            if r < 128:
+                continue
+            c = channels(r)
+            buf, p0, ps, rs = _native.aligned_rows_buffer(B, c, r + 1, r + 1, 1, d)
+            buf.normal_()
+            noise = torch.randn(B, 1, r, r, device=d)
+            nw = torch.full((1,), 0.1, device=d)
+            bias = torch.randn(c, device=d)
+            fn = lambda: _native.blur_noise_bias_act(p0, d, B, c, r + 1, r + 1, ps, rs, k, (1, 1), noise, nw, bias, 0.2, 2 ** 0.5)
+            if fn() is None:
+                continue
+            ms, mn = timeit(fn)
+            gb = 4.0 * B * c * ((r + 1) ** 2 + r * r) / 1e9
+            print(f'  res {r:5d} C {c:4d}: {ms * 1e3:9.1f} us  {gb / ms * 1e3:8.1f} GB/s  (min {mn * 1e3:.1f} us)')
     if 'io' in what:
         print('== input/output pipeline (uint8 images <-> tensors)')
         for b, hin, hout in ((32, 1024, 256), (32, 512, 256), (8, 1024, 1024), (32, 256, 256)):

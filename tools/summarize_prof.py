@@ -22,7 +22,15 @@ def main(out):
     print(f'# rocprofv3 summary: {os.path.basename(out)}\n')
     for f in find(os.path.join(out, 'trace'), '*kernel_stats.csv'):
         rows = list(csv.DictReader(open(f)))
-        print('## kernel-trace --stats (all kernels, whole run)\n')
+        # MIOpen's exhaustive find (torch.backends.cudnn.benchmark) times every applicable solver once per process,
+        # including its naive reference convs; those launches happen before the timed region and are listed apart
+        find_rows = [r for r in rows if r['Name'].startswith('naive_conv')]
+        rows = [r for r in rows if not r['Name'].startswith('naive_conv')]
+        print('## kernel-trace --stats (whole run: warm-up + MIOpen find + timed steps)\n')
+        if find_rows:
+            ms = sum(float(r['TotalDurationNs']) for r in find_rows) / 1e6
+            print(f'(excluded: {sum(int(r["Calls"]) for r in find_rows)} launches / {ms:.0f} ms of MIOpen naive_conv_* '
+                  f'kernels run by the one-off solver search during warm-up; percentages below are of the whole run)\n')
         print('| kernel | calls | total ms | avg us | % |')
         print('|---|---|---|---|---|')
         for r in rows[:40]:
@@ -50,8 +58,12 @@ def main(out):
         marks = [i for i, r in enumerate(rows) if 'ufd_rowmarch_f32<4' in r['Kernel_Name']]
         big = max((int(rows[i]['Grid_Size_X']) for i in marks), default=0)
         marks = [i for i in marks if int(rows[i]['Grid_Size_X']) == big]
-        if len(marks) >= 3:
-            step = rows[marks[-3]:marks[-2]]
+        # bench.py also launches the headline blur back to back (standalone roofline): a step is a pair of marks
+        # more than 5 ms apart
+        pairs = [(a, b) for a, b in zip(marks, marks[1:])
+                 if int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp']) > 5_000_000]
+        if len(pairs) >= 2:
+            step = rows[pairs[-2][0]:pairs[-2][1]]
             t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
             agg = defaultdict(lambda: [0, 0])
             for r in step:
@@ -84,5 +96,42 @@ def main(out):
             print()
 
 
+def headline_traffic(out, tag):
+    """HBM-side bytes of the headline blur per launch from the two PMC passes, split into the launches inside a step
+    (fused noise/bias/lrelu store, strided input) and bench.py's standalone back-to-back launches of the plain op."""
+    import json
+    res = {}
+    for sub, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+        for f in find(os.path.join(out, sub), '*counter_collection.csv'):
+            vals = sorted((int(r['Dispatch_Id']), float(r['Counter_Value'])) for r in csv.DictReader(open(f))
+                          if r['Counter_Name'] == ctr and 'ufd_rowmarch_f32<4' in r['Kernel_Name'] and r['Grid_Size'] == '1048576')
+            insitu = [v for i, (d, v) in enumerate(vals)
+                      if (i == 0 or d - vals[i - 1][0] > 50) and (i + 1 == len(vals) or vals[i + 1][0] - d > 50)]
+            alone = [v for d, v in vals if v not in insitu]
+            res[ctr] = (insitu, alone)
+    if len(res) < 2:
+        return
+    def mb(fetch, write):
+        return (2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0
+    fi, fa = res['FETCH_SIZE']
+    wi, wa = res['WRITE_SIZE']
+    doc = {
+        'kernel': 'ufd_rowmarch_f32<4,true> [256,1025,1025]->[256,1024,1024] (grid 1048576 threads)',
+        'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact',
+        'in_step': {'what': 'blur + fused noise/bias/lrelu store, aligned-row strided input (as launched by StyledConv)',
+                    'FETCH_SIZE_KiB_per_launch': sum(fi) / len(fi), 'WRITE_SIZE_KiB_per_launch': sum(wi) / len(wi),
+                    'launches_sampled': [len(fi), len(wi)], 'hbm_bytes_per_launch': mb(fi, wi)},
+        'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py, tools/profile_gpu.sh {tag}',
+    }
+    if fa and wa:
+        doc['standalone_op'] = {'what': 'op.upfirdn2d, contiguous input, no epilogue (bench.py roofline_upfirdn2d_op)',
+                                'FETCH_SIZE_KiB_per_launch': sum(fa) / len(fa), 'WRITE_SIZE_KiB_per_launch': sum(wa) / len(wa),
+                                'launches_sampled': [len(fa), len(wa)], 'hbm_bytes_per_launch': mb(fa, wa)}
+    doc['hbm_bytes_per_launch'] = doc['in_step']['hbm_bytes_per_launch']
+    with open(os.path.join(out, 'headline_traffic.json'), 'w') as fh:
+        json.dump(doc, fh, indent=1)
+
+
 if __name__ == '__main__':
     main(sys.argv[1])
+    headline_traffic(sys.argv[1], os.path.basename(sys.argv[1].rstrip('/')).replace('prof_', ''))
