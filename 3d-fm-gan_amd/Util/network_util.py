@@ -4,6 +4,8 @@ Kept for the callers (train_3_encoder.py:460,507,574; Evaluation/visual_eval.py:
 Forward_Inference_3_Encoder, Build_Generator_From_Dict, Get_Network_Shape, Get_Conv_Kernel_Key.
 Image/PIL helpers of the reference file (torchvision-based) are not on the path and not provided.
 """
+import os
+
 import torch
 
 from stylegan2 import Generator
@@ -38,6 +40,44 @@ def _unwrapped(net):
     return getattr(net, 'module', net)
 
 
+PIPELINE = os.environ.get('FMGAN_NO_PIPELINE', '0') != '1'
+# Side streams share the device's 4 hardware queues with the main stream: measured on MI355X (pairs1024), ResNets on
+# one stream + 2 head streams 339.8 pairs/s; 2 + 2: 335; 2 + 4: 325; 8 hardware queues (GPU_MAX_HW_QUEUES): 246.
+RESNET_STREAMS = int(os.environ.get('FMGAN_RESNET_STREAMS', '1'))
+
+
+def _pipelined(p_input, r_input, tsr_input, E_Tsr, E_W, e_wp, g_ema, sliced_layer, use_tanh):
+    """Inference schedule of Forward_Inference_3_Encoder: the synthesis network consumes W+ one column per layer, so it
+    starts as soon as the first style heads of the pSp encoder are done and runs beside the remaining heads (each a
+    large conv followed by a tail of tiny launches) instead of after all of them.  Same arithmetic per element as the
+    serial form: latent[:, i] = W * W+[:, i] (or W), image = g(latent, tsr)."""
+    rs = side_streams(p_input.device, RESNET_STREAMS, 'resnets')
+    s1, s2 = rs[0], rs[-1]
+    join1, encoded_tensor = run_on(s1, E_Tsr, tsr_input)
+    join2, encoded_W = run_on(s2, E_W, r_input)
+    heads = e_wp.forward_deferred(p_input)
+    join1(); join2()
+    n_styles = len(heads)
+    g = _unwrapped(g_ema)
+    if sliced_layer is None:
+        sliced_layer = range(g.n_latent)
+    sliced = {i for i in sliced_layer if 0 <= i < n_styles}
+    cache = {}
+
+    def column(i):
+        if i not in cache:
+            wait, wp = heads[i]
+            wait()
+            cache[i] = encoded_W * wp if i in sliced else encoded_W
+        return cache[i]
+
+    g_output = g_ema(noise_z=None, use_external_input_tensor=True, external_input_tensor=encoded_tensor,
+                     latent_columns=column)
+    for wait, _ in heads:          # columns the generator did not read: still join their streams
+        wait()
+    return torch.tanh(g_output) if use_tanh else g_output
+
+
 def Forward_Inference_3_Encoder(p_input, r_input, E_Tsr, E_W, E_W_Plus, g_ema, tsr_encode='Photo Image',
                                 sliced_layer=None, use_tanh=False, PPL_regularize=False):
     """One forward of the 3-encoder scheme with multiplicative co-modulation (Util/network_util.py:293-338).
@@ -48,11 +88,14 @@ def Forward_Inference_3_Encoder(p_input, r_input, E_Tsr, E_W, E_W_Plus, g_ema, t
     if tsr_encode not in MODULATION_ENCODING:
         raise ValueError(f'tsr_encode must be one of {MODULATION_ENCODING}')
     tsr_input = p_input if tsr_encode == 'Photo Image' else r_input
+    if (PIPELINE and overlap_ok(p_input) and not PPL_regularize and hasattr(_unwrapped(E_W_Plus), 'forward_deferred')
+            and isinstance(_unwrapped(g_ema), Generator)):
+        return _pipelined(p_input, r_input, tsr_input, E_Tsr, E_W, _unwrapped(E_W_Plus), g_ema, sliced_layer, use_tanh)
     if overlap_ok(p_input):
         # the three encoders are independent: the two small ResNets run on side streams beside the pSp encoder
-        s1, s2 = side_streams(p_input.device, 2)
-        join1, encoded_tensor = run_on(s1, E_Tsr, tsr_input)
-        join2, encoded_W = run_on(s2, E_W, r_input)
+        rs = side_streams(p_input.device, RESNET_STREAMS, 'resnets')
+        join1, encoded_tensor = run_on(rs[0], E_Tsr, tsr_input)
+        join2, encoded_W = run_on(rs[-1], E_W, r_input)
         encoded_W_plus = E_W_Plus(p_input)
         join1(); join2()
     else:

@@ -18,8 +18,10 @@ def overlap_ok(t):
     return ENABLED and t.is_cuda and not torch.is_grad_enabled()
 
 
-def side_streams(device, n):
-    key = (device.type, device.index)
+def side_streams(device, n, group='default'):
+    """n side streams of a named group (groups do not share streams: work queued for one branch never sits in front
+    of another branch's launches)."""
+    key = (device.type, device.index, group)
     pool = _POOL.setdefault(key, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
@@ -49,3 +51,23 @@ def run_on(stream, fn, *args):
         _record(out, main)            # outputs were allocated on `stream`: they are consumed on `main`
 
     return join, out
+
+
+def run_deferred(stream, fn, *args):
+    """Like run_on, but the join is an event recorded right after fn's launches: wait() makes the CURRENT stream wait
+    for this call only, not for whatever is queued on `stream` afterwards.  Returns (wait, result)."""
+    main = torch.cuda.current_stream(stream.device)
+    stream.wait_stream(main)
+    for a in args:
+        _record(a, stream)
+    with torch.cuda.stream(stream):
+        out = fn(*args)
+        done = torch.cuda.Event()
+        done.record(stream)
+
+    def wait():
+        cur = torch.cuda.current_stream(stream.device)
+        cur.wait_event(done)
+        _record(out, cur)
+
+    return wait, out

@@ -18,12 +18,14 @@ from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
 from .helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
 from stylegan2 import EqualLinear
 from op import fused_leaky_relu
-from Util.streams import overlap_ok, run_on, side_streams
+from Util.streams import overlap_ok, run_deferred, side_streams
 
 # Inference: the style heads are independent of each other and each ends in a tail of tiny launches (conv at 16^2 ... 1^2
 # + bias + LeakyReLU, ~25 kernels of a few microseconds) that cannot fill 256 CUs; heads are dealt round-robin onto
-# this many side streams so the tails overlap other heads' large first convs and the pyramid's lateral layers.
-HEAD_STREAMS = int(os.environ.get('FMGAN_PSP_STREAMS', '4'))
+# this many side streams so the tails overlap other heads' large first convs, the pyramid's lateral layers and — through
+# forward_deferred — the synthesis network.  2 streams measured best (more streams than hardware queues serialise
+# behind each other: 4 streams 325, 3 streams 331-340, 2 streams 337-340 pairs/s).
+HEAD_STREAMS = int(os.environ.get('FMGAN_PSP_STREAMS', '2'))
 
 _TAPS = {18: (3, 5, 7), 50: (6, 20, 23)}   # units whose outputs feed the pyramid (psp_encoders.py:105-108)
 
@@ -94,6 +96,16 @@ class GradualStyleEncoder(Module):
         return F.interpolate(x, size=y.shape[2:], mode='bilinear', align_corners=True) + y
 
     def forward(self, x):
+        heads = self.forward_deferred(x)
+        for wait, _ in heads:
+            wait()
+        return torch.stack([t for _, t in heads], dim=1)
+
+    def forward_deferred(self, x):
+        """The n_styles latents [B,512] as a list of (wait, tensor): call wait() before the current stream reads the
+        tensor.  In inference on the GPU the heads run on side streams and wait() is a per-head event, so a consumer
+        that needs the latents one layer at a time (the synthesis network) starts while later heads are still running;
+        otherwise everything runs in order and wait() does nothing."""
         if self.channels_last and x.is_cuda:
             self._to_channels_last()
             x = x.contiguous(memory_format=torch.channels_last)
@@ -105,22 +117,17 @@ class GradualStyleEncoder(Module):
             if i in (t1, t2, t3):
                 feats[i] = x
         c1, c2, c3 = feats[t1], feats[t2], feats[t3]
-        joins = []
         if HEAD_STREAMS > 1 and overlap_ok(x):
-            streams = side_streams(x.device, HEAD_STREAMS)
+            streams = side_streams(x.device, HEAD_STREAMS, 'psp-heads')
 
             def head(j, feat):
-                join, out = run_on(streams[j % HEAD_STREAMS], self.styles[j], feat)
-                joins.append(join)
-                return out
+                return run_deferred(streams[j % HEAD_STREAMS], self.styles[j], feat)
         else:
             def head(j, feat):
-                return self.styles[j](feat)
+                return (lambda: None), self.styles[j](feat)
         latents = [head(j, c3) for j in range(min(self.coarse_ind, self.style_count))]
         p2 = self._upsample_add(c3, self.latlayer1(c2))
         latents += [head(j, p2) for j in range(self.coarse_ind, min(self.middle_ind, self.style_count))]
         p1 = self._upsample_add(p2, self.latlayer2(c1))
         latents += [head(j, p1) for j in range(self.middle_ind, self.style_count)]
-        for join in joins:
-            join()
-        return torch.stack(latents, dim=1)
+        return latents

@@ -343,6 +343,21 @@ class ToRGB(nn.Module):
         return out
 
 
+class _LatentColumns:
+    """W+ given one column at a time: latent[:, i] calls provider(i) (which may first wait for the stream that is
+    still producing that column).  Used by Forward_Inference_3_Encoder to start the synthesis network before the last
+    style heads of the encoder have finished."""
+
+    def __init__(self, provider, n_latent):
+        self.provider, self.n = provider, n_latent
+
+    def __getitem__(self, idx):
+        col = idx[1]
+        if not (isinstance(idx, tuple) and isinstance(col, int) and idx[0] == slice(None)):
+            raise IndexError('only latent[:, i] is served column-wise')
+        return self.provider(col)
+
+
 class Generator(nn.Module):
     """StyleGAN2 synthesis (+ mapping) network with the 3D-FM GAN extensions: external 4x4 input tensor, W+ input,
     in-forward path-length regulariser, RGB pyramid and style-scalar outputs (stylegan2.py:407-688)."""
@@ -416,16 +431,26 @@ class Generator(nn.Module):
     def forward(self, noise_z, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                 latent_styles=None, input_is_latent=False, noise=None, randomize_noise=True,
                 use_external_input_tensor=False, external_input_tensor=None, PPL_regularize=False,
-                return_rgb_list=False, return_style_scalars=False):
-        styles = latent_styles if input_is_latent else [self.style(z) for z in noise_z]
+                return_rgb_list=False, return_style_scalars=False, latent_columns=None):
+        """latent_columns (not in the reference): callable i -> W+[:, i] replacing latent_styles; inference only, with
+        an external input tensor (see _LatentColumns)."""
+        if latent_columns is not None:
+            if PPL_regularize or return_latents or return_style_scalars or not use_external_input_tensor:
+                raise ValueError('latent_columns serves the plain inference forward only')
+            styles = None
+        else:
+            styles = latent_styles if input_is_latent else [self.style(z) for z in noise_z]
         if noise is None:
             if randomize_noise:
                 noise = [None] * self.num_layers
             else:
                 noise = [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
-        if truncation < 1:
-            styles = [truncation_latent + truncation * (w - truncation_latent) for w in styles]
-        latent = self._latents(styles, inject_index)
+        if latent_columns is not None:
+            latent = _LatentColumns(latent_columns, self.n_latent)
+        else:
+            if truncation < 1:
+                styles = [truncation_latent + truncation * (w - truncation_latent) for w in styles]
+            latent = self._latents(styles, inject_index)
 
         if use_external_input_tensor:
             assert external_input_tensor is not None
