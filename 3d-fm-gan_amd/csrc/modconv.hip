@@ -157,7 +157,11 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // Persistent tiles for the short-K layers (a block walks 2-8 tiles and loads the next tile's first chunk under the
 // current tile's last chunk / epilogue) were also measured: 56-88 vs 68-97 TFLOP/s on the 512^2-1024^2 layers —
 // holding the prefetched chunk across the epilogue spills 20-70 VGPRs, and the two co-resident blocks per SIMD
-// already overlap one block's prologue/epilogue with the other's MFMAs.  Not kept.)
+// already overlap one block's prologue/epilogue with the other's MFMAs.  Not kept.
+// Two LDS images with ONE barrier per chunk, keeping two blocks per CU (possible for the 64- and 32-channel tiles and
+// both transposed tiles: <= 39 KB per image): issue(c+1); MFMAs(c); commit(c+1 -> other image); barrier.  Measured
+// slower on every layer it applies to (transposed 128^2..512^2: 860/850/940 vs 812/793/893 us; plain 1024^2: 1713 vs
+// 1673 us).  Not kept.)
 template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false>
 __global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
   static_assert(!RGB || MODE == 0, "the RGB epilogue belongs to the plain conv");
