@@ -252,3 +252,31 @@ def test_overlapped_and_graphed_forward_equal_serial():
     torch.testing.assert_close(fwd(p, r), f_serial, **tol)
     gf = GraphedForward(fwd, (p, r))
     torch.testing.assert_close(gf(p, r), f_serial, **tol)
+
+
+def test_pipelined_forward_matches_serial_for_partial_slices_and_tanh():
+    """The inference schedule (synthesis network behind per-head events of the pSp encoder, Util/network_util._pipelined)
+    must equal the single-stream composition for any sliced_layer subset (W * W+ only on those layers), with tanh,
+    and when the generator has fewer layers than the encoder has style heads."""
+    import stylegan2
+    from Util import streams
+    from Util.network_util import Forward_Inference_3_Encoder
+    e_tsr, e_w, e_wp = _encoders(10)                               # 10 style heads
+    G = _load(stylegan2.Generator(32, 512, 2), 'generator', 21)    # n_latent = 8 < 10
+    wrap = _PinNoise(G)
+    p = synth.tensor('pipe/photo', (3, 3, 256, 256), dist='uniform').to(dev())
+    r = synth.tensor('pipe/render', (3, 3, 256, 256), dist='uniform').to(dev())
+    for sliced, tanh in ((None, False), ([0, 3, 4], True), ([], False), (range(2, 20), True)):
+        with torch.no_grad():
+            fast = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, wrap, sliced_layer=sliced, use_tanh=tanh).clone()
+            try:
+                streams.ENABLED = False
+                slow = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, wrap, sliced_layer=sliced, use_tanh=tanh)
+            finally:
+                streams.ENABLED = True
+        torch.testing.assert_close(fast, slow, atol=1e-4 * float(slow.abs().max()), rtol=1e-4)
+    # render image as the tensor-encoder input
+    with torch.no_grad():
+        a = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, wrap, tsr_encode='Render Image')
+        b = Forward_Inference_3_Encoder(r, r, e_tsr, e_w, e_wp, wrap)            # photo := render for E_Tsr only...
+    assert tuple(a.shape) == (3, 3, 32, 32) and not torch.equal(a, b)
