@@ -203,8 +203,10 @@ def main():
 
     from Miscellaneous import distributed as D
     from op import _native
-    # let MIOpen pick each encoder convolution's kernel by measurement during warm-up (pSp encoder 10.7 -> 9.9 ms)
-    torch.backends.cudnn.benchmark = True
+    # let MIOpen pick each encoder convolution's kernel by measurement during warm-up (pSp encoder 10.7 -> 9.9 ms).
+    # Forward workloads only: the exhaustive search over every backward-data / weight-gradient solver of the training
+    # workload (it times MIOpen's naive reference kernels too) takes more than 7 minutes of warm-up.
+    torch.backends.cudnn.benchmark = args.workload != 'train256'
     rank, world, device = D.init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
