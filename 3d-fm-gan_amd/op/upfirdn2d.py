@@ -59,7 +59,8 @@ class UpFirDn2d(Function):
         kh, kw = kernel.shape
         out = upfirdn2d_op.upfirdn2d(input.reshape(-1, in_h, in_w, 1), kernel, up[0], up[1], down[0], down[1], *pad)
         out_h, out_w = out.shape[1], out.shape[2]
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        if ctx.needs_input_grad[0]:      # (inference never reads the flipped taps: one launch less per call)
+            ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
         ctx.cfg = (up, down, pad, _adjoint_pads(in_h, in_w, out_h, out_w, kh, kw, up, down, pad),
                    tuple(input.shape), (out_h, out_w))
         return out.view(-1, channel, out_h, out_w)
