@@ -323,3 +323,26 @@ def test_tensor2im_bit_exact():
     from Util.image_io import images_to_tensor
     back = tensor2im_batch(images_to_tensor(u8.to(dev()))).cpu()
     assert int((back.int() - u8.int()).abs().max()) <= 1
+
+
+def test_empty_batches_are_no_ops():
+    """Zero-sized leading dimension: every entry point returns an empty result without launching (the reference's ops
+    accept empty tensors the same way: at::empty + a zero-block launch guard)."""
+    from op import _native, upfirdn2d, fused_leaky_relu
+    d = dev()
+    k = torch.ones(4, 4, device=d) / 16
+    y = upfirdn2d(torch.zeros(0, 3, 8, 8, device=d), k, pad=(2, 1))
+    assert tuple(y.shape) == (0, 3, 8, 8)
+    y = fused_leaky_relu(torch.zeros(0, 5, 4, 4, device=d), torch.zeros(5, device=d))
+    assert tuple(y.shape) == (0, 5, 4, 4)
+    wt = _native.modconv_weight_prep(torch.randn(6, 4, 3, 3, device=d), 0.1)
+    for mode, shape in ((0, (0, 6, 8, 8)), (1, (0, 6, 17, 17)), (2, (0, 6, 3, 3))):
+        out = _native.modconv2d(torch.zeros(0, 4, 8, 8, device=d), wt, torch.zeros(0, 4, device=d), None, mode)
+        assert tuple(out.shape) == shape
+    assert tuple(_native.modconv_demod(torch.randn(6, 4, 3, 3, device=d), torch.zeros(0, 4, device=d), 0.1).shape) == (0, 6)
+    rgb = _native.torgb(torch.zeros(0, 4, 8, 8, device=d), torch.randn(3, 4, device=d), torch.zeros(0, 4, device=d),
+                        torch.zeros(3, device=d), None, 0.5)
+    assert tuple(rgb.shape) == (0, 3, 8, 8)
+    assert tuple(_native.images_to_tensor(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device=d)).shape) == (0, 3, 8, 8)
+    assert tuple(_native.tensor_to_images(torch.zeros(0, 3, 8, 8, device=d)).shape) == (0, 8, 8, 3)
+    assert tuple(_native.resize_images(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device=d), 4, 4).shape) == (0, 4, 4, 3)
