@@ -162,8 +162,8 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // both transposed tiles: <= 39 KB per image): issue(c+1); MFMAs(c); commit(c+1 -> other image); barrier.  Measured
 // slower on every layer it applies to (transposed 128^2..512^2: 860/850/940 vs 812/793/893 us; plain 1024^2: 1713 vs
 // 1673 us).  Not kept.)
-template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false>
-__global__ __launch_bounds__(256, 2) void modconv_mfma_f32(const MCParams p) {
+template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) {
   static_assert(!RGB || MODE == 0, "the RGB epilogue belongs to the plain conv");
   constexpr int KC = MC_KC;
   constexpr int BM = 32 * RM * WM;
@@ -604,7 +604,7 @@ inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
   return (long long)sg.tiles_x * sg.tiles_y * sg.tiles_b;
 }
 
-template <int MODE, int RM, int RNP, int WM, int WN>
+template <int MODE, int RM, int RNP, int WM, int WN, int MINB = 2>
 int launch_cfg(MCParams& p, hipStream_t s) {
   if constexpr (MODE != 0) { if (p.rgb_out) return FMGAN_EUNSUPPORTED; }
   constexpr int BM = 32 * RM * WM, BN = 32 * RNP * WN;
@@ -625,43 +625,49 @@ int launch_cfg(MCParams& p, hipStream_t s) {
   if constexpr (MODE == 0) {
     if (p.rgb_out) {
       if (p.o_tiles != 1 || p.ksplit != 1) return FMGAN_EUNSUPPORTED;
-      hipLaunchKernelGGL((modconv_mfma_f32<0, RM, RNP, WM, WN, true>), dim3((unsigned)blocks, 1), dim3(256), lds, s, p);
+      hipLaunchKernelGGL((modconv_mfma_f32<0, RM, RNP, WM, WN, true, MINB>), dim3((unsigned)blocks, 1), dim3(256), lds, s, p);
       return fmgan_check_launch();
     }
   }
-  hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RNP, WM, WN>), dim3((unsigned)blocks, p.ksplit), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RNP, WM, WN, false, MINB>), dim3((unsigned)blocks, p.ksplit), dim3(256), lds, s, p);
   return fmgan_check_launch();
 }
 
-// tile configuration: 0 = 128(o) x 128(pos), 1 = 64 x 256 (mode 1: 64 x 128), 2 = 32 x 512 (mode 1: 32 x 256), 3 = 32 x 128
+// Tile configurations (output channels x positions per block; blocks per CU the register budget allows):
+//   mode 0: 0 = 128 x 128 (2 per CU), 1 = 64 x 128 (3 per CU), 2 = 32 x 128 (4 per CU)
+//   mode 2: 0 = 128 x 128, 1 = 64 x 128, 2 = 32 x 128
+//   mode 1: 1 = 64 x 128 (2 per CU; 4 phases = 128 accumulator registers), 2 = 32 x 128 (3 per CU)
+// For Cout < 96 larger position tiles (64 x 256, 32 x 512; mode 1: 32 x 256) were the first design: fewer weight
+// re-reads per MFMA, but 245-256 VGPRs and only two blocks per CU.  On these short-K layers (4-16 chunks per block) more
+// co-resident blocks hide the prologue/epilogue better: 1024^2 plain 1681 -> 1597 us, 1024^2 transposed 980 -> 894 us,
+// 512^2 plain 1440 -> 1403 us (B=8).  The same trade for Cout >= 96 loses (64 x 128 x 3: 1283 vs 1233 us at 64^2), and
+// 32 x 128 tiles for the transposed conv at Cout >= 48 are a wash (+-3 %, sign depends on batch), so those stay.
 inline int pick_cfg(int mode, int cout, long long positions) {
   if (mode == 0) {
-    if (positions <= 2048) return 3;          // tiny layers: many small tiles (+ split-K)
+    if (positions <= 2048) return 2;          // tiny layers: many small tiles (+ split-K)
     return cout >= 96 ? 0 : (cout >= 48 ? 1 : 2);
   }
-  if (mode == 2) return cout >= 96 ? 0 : (cout >= 48 ? 1 : 3);   // stride-2 patches are 4x larger: 128 positions only
+  if (mode == 2) return cout >= 96 ? 0 : (cout >= 48 ? 1 : 2);   // stride-2 patches are 4x larger: 128 positions only
   return cout >= 48 ? 1 : 2;
 }
 
 inline void cfg_dims(int mode, int cfg, int& BM, int& BN) {
-  if (mode == 0) {
-    const int bm[4] = {128, 64, 32, 32}, bn[4] = {128, 256, 512, 128};
-    BM = bm[cfg]; BN = bn[cfg];
-  } else if (mode == 2) {
-    const int bm[4] = {128, 64, 32, 32};
-    BM = bm[cfg]; BN = 128;
-  } else {
-    BM = cfg == 1 ? 64 : 32; BN = cfg == 1 ? 128 : 256;
-  }
+  (void)mode;
+  const int bm[3] = {128, 64, 32};
+  BM = bm[cfg]; BN = 128;
+}
+
+inline int cfg_blocks_per_cu(int mode, int cfg) {
+  if (mode == 1) return cfg == 2 ? 3 : 2;
+  return cfg == 0 ? 2 : (cfg == 1 ? (mode == 0 ? 3 : 2) : 4);
 }
 
 inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
   if (mode == 0) {
     switch (cfg) {
       case 0: return launch_cfg<0, 2, 2, 2, 2>(p, s);
-      case 1: return launch_cfg<0, 2, 2, 1, 4>(p, s);
-      case 2: return launch_cfg<0, 1, 4, 1, 4>(p, s);
-      default: return launch_cfg<0, 1, 1, 1, 4>(p, s);
+      case 1: return launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
+      default: return launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
     }
   }
   if (mode == 2) {
@@ -671,7 +677,7 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
       default: return launch_cfg<2, 1, 1, 1, 4>(p, s);
     }
   }
-  return cfg == 1 ? launch_cfg<1, 2, 1, 1, 4>(p, s) : launch_cfg<1, 1, 2, 1, 4>(p, s);
+  return cfg == 1 ? launch_cfg<1, 2, 1, 1, 4>(p, s) : launch_cfg<1, 1, 1, 1, 4, 3>(p, s);
 }
 
 // Blocks of one launch (all segments), for a given tile configuration.
@@ -701,7 +707,7 @@ inline int pick_ksplit(int mode, int batch, int cin, int cout, int h, int w) {
   const int cfg = pick_cfg(mode, cout, (long long)batch * poh * pow_);
   const long long blocks = count_blocks(mode, cfg, batch, cout, h, w);
   const int chunks = (cin + MC_KC - 1) / MC_KC;
-  const int slots = FMGAN_NUM_CU * ((mode == 0 && cfg == 3) ? 4 : 2);   // co-resident blocks (VGPR-limited)
+  const int slots = FMGAN_NUM_CU * cfg_blocks_per_cu(mode, cfg);   // co-resident blocks (VGPR-limited)
   if (blocks >= 4LL * slots || chunks < 4) return 1;
   int BM, BN;
   cfg_dims(mode, cfg, BM, BN);
@@ -1029,7 +1035,7 @@ bool rgb_fusable(int batch, int cin, int cout, int h, int w) {
   MCParams::Seg sg{0, 0, h, w};
   plan_segment(sg, batch, BN);
   // one output-channel tile, tiles of a single sample; the fused launch runs without split-K
-  return cfg <= 2 && cout <= BM && sg.nb == 1;
+  return cout <= BM && sg.nb == 1;
 }
 
 __global__ __launch_bounds__(256) void torgb_weight_mod_f32(const float* __restrict__ W, const float* __restrict__ style,

@@ -78,7 +78,7 @@ def test_modconv_kernel_vs_c_oracle(cfg, demod):
 
 
 @pytest.mark.parametrize('cfg', [
-    # (batch, cin, cout, h, w, keep_out): cout <= 32 -> 32x512 tile, <= 64 -> 64x256, <= 128 -> 128x128 (two channel waves)
+    # (batch, cin, cout, h, w, keep_out): cout <= 32 -> 32x128 tile, <= 64 -> 64x128, <= 128 -> 128x128 (two channel waves)
     (2, 32, 32, 64, 64, True), (1, 24, 20, 70, 66, True), (2, 16, 32, 128, 128, False),
     (2, 64, 64, 48, 48, True), (1, 40, 50, 75, 61, False),
     (2, 128, 128, 40, 40, True), (1, 72, 100, 49, 57, False), (3, 16, 128, 32, 32, True),
