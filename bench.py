@@ -7,7 +7,8 @@ A "step" is one forward of the hot path over one batch of synthetic (photo, rend
 E_Tsr + E_W + E_W_Plus on 256^2 images -> co-modulation -> Generator -> image, fp32, eval-mode BatchNorm, no_grad.
 Default workload `pairs1024` is BASELINE config 4's per-GPU shard (B=8/GPU, Generator(1024), 18 styles — encoders on
 256^2, SURVEY F5), the configuration the headline upfirdn2d call ([B*32,1025,1025] -> [B*32,1024,1024]) lives in;
-`pairs256` (B=32/GPU, Generator(256)) is timed in the same run and reported as `pairs_per_s_256`.
+`pairs256` (B=32/GPU, Generator(256)) is timed in the same run and reported as `pairs_per_s_256`, and BASELINE
+config 2 (Generator(256) alone on random W+, B=32) as `synthesis256_images_per_s`.
 Forward shards over ranks by batch with no collective: weak scaling, value = all ranks' pairs / max time.
 Prints ONE JSON line on rank 0.
 """
@@ -338,7 +339,20 @@ def main():
         out['pairs_per_s_256'] = world * wl2['batch'] * args.steps / dt2
         out['ms_per_step_256'] = 1e3 * dt2 / args.steps
         out['config']['secondary'] = f"pairs256: {wl2['desc']}"
-        del nets2, step2
+        # BASELINE config 2: synthesis network only, random W+ and input tensor, batch 32 @256^2
+        g2net = nets2['g']
+        gen2 = torch.Generator(device='cpu').manual_seed(4321 + rank)
+        lat2 = torch.randn(wl2['batch'], g2net.n_latent, 512, generator=gen2).to(device)
+        tsr2 = torch.randn(wl2['batch'], 512, 4, 4, generator=gen2).to(device)
+
+        def synth_step():
+            with torch.no_grad():
+                return g2net(None, latent_styles=[lat2], input_is_latent=True, use_external_input_tensor=True,
+                             external_input_tensor=tsr2)
+        dt3 = timed(synth_step, args.steps, args.warmup, world)
+        out['synthesis256_images_per_s'] = world * wl2['batch'] * args.steps / dt3
+        out['config']['tertiary'] = 'cfg2: Generator(256) only, random W+ [32,14,512] and input tensor, fp32, B=32/GPU'
+        del nets2, step2, g2net
         torch.cuda.empty_cache()
         nets = build_models(wl['size'], device)
         _, inputs = make_step(nets, 1, device, rank)
