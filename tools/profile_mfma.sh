@@ -18,7 +18,7 @@ for tag in ('pmc_mfma', 'pmc_mfma2'):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
         if 'modconv_mfma' in r['Kernel_Name']:
-            agg[(r['Kernel_Name'][:60], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+            agg[(r["Kernel_Name"][:75], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
     print('##', tag)
     for k, v in sorted(agg.items(), key=lambda kv: -max(sum(x) for x in kv[1].values()))[:14]:
         print(k, {c: round(sum(x) / len(x)) for c, x in v.items()})
