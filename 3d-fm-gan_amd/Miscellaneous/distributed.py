@@ -153,6 +153,11 @@ def data_parallel(module, device=None, overlap=True, find_unused_parameters=True
     use_external_input_tensor=True; Util/network_util.py:329-330) — DDP would otherwise stall on their buckets."""
     if device is not None:
         module = module.to(device)
+    # modules that re-lay their conv weights for the GPU (pSp encoder: NHWC) do it now, so that DDP's bucket views are
+    # built for the final parameter strides
+    relayout = getattr(module, '_to_channels_last', None)
+    if relayout is not None and getattr(module, 'channels_last', False) and next(module.parameters()).is_cuda:
+        relayout()
     if _active() and get_world_size() > 1 and overlap and any(p.requires_grad for p in module.parameters()):
         ids = [device.index] if (device is not None and device.type == 'cuda') else None
         return nn.parallel.DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=256,
