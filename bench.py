@@ -202,6 +202,9 @@ def main():
                     'value (measured: no gain at these sizes, the step is GPU-bound)')
     args = ap.parse_args()
 
+    import __graft_entry__
+    # harness convenience on a fresh checkout (the product itself never builds): local rank 0 compiles, the others wait
+    __graft_entry__.ensure_built(builder=int(os.environ.get('LOCAL_RANK', '0')) == 0)
     from Miscellaneous import distributed as D
     from op import _native
     # let MIOpen pick each encoder convolution's kernel by measurement during warm-up (pSp encoder 10.7 -> 9.9 ms).

@@ -14,6 +14,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import __graft_entry__
+    __graft_entry__.ensure_built()      # fresh checkout: compile libfmgan_hip.so + the oracle once (hipcc needs no GPU)
 
 
 def pytest_collection_modifyitems(config, items):
