@@ -161,7 +161,10 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // Two LDS images with ONE barrier per chunk, keeping two blocks per CU (possible for the 64- and 32-channel tiles and
 // both transposed tiles: <= 39 KB per image): issue(c+1); MFMAs(c); commit(c+1 -> other image); barrier.  Measured
 // slower on every layer it applies to (transposed 128^2..512^2: 860/850/940 vs 812/793/893 us; plain 1024^2: 1713 vs
-// 1673 us).  Not kept.)
+// 1673 us).  Not kept.
+// Interleaving the two 32-channel halves of each 64-channel group in the LDS weight image (so the RM = 2 tiles read
+// both A operands of a tap with one ds_read_b64: 25-40 % fewer LDS read instructions, same loads and writes) changed
+// nothing measurable (+-1 %): the count of A-operand reads is not what limits the MFMA rate.  Not kept.)
 template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) {
   static_assert(!RGB || MODE == 0, "the RGB epilogue belongs to the plain conv");
