@@ -24,6 +24,10 @@ for _p in (ROOT, os.path.join(ROOT, '3d-fm-gan_amd'), os.path.join(ROOT, 'tests'
     if _p not in sys.path:
         sys.path.insert(0, _p)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# MIOpen's solver search (cudnn.benchmark, forward workloads) otherwise also times its naive reference convolutions —
+# 2.5 s of GPU time per process that can never win; leaving them out shortens the warm-up (same kernels get picked).
+for _v in ('FWD', 'BWD', 'WRW'):
+    os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + _v, '0')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
