@@ -24,10 +24,6 @@ for _p in (ROOT, os.path.join(ROOT, '3d-fm-gan_amd'), os.path.join(ROOT, 'tests'
     if _p not in sys.path:
         sys.path.insert(0, _p)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-# MIOpen's solver search (cudnn.benchmark, forward workloads) otherwise also times its naive reference convolutions —
-# 2.5 s of GPU time per process that can never win; leaving them out shortens the warm-up (same kernels get picked).
-for _v in ('FWD', 'BWD', 'WRW'):
-    os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + _v, '0')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -215,6 +211,10 @@ def main():
     # Forward workloads only: the exhaustive search over every backward-data / weight-gradient solver of the training
     # workload (it times MIOpen's naive reference kernels too) takes more than 7 minutes of warm-up.
     torch.backends.cudnn.benchmark = args.workload != 'train256'
+    if torch.backends.cudnn.benchmark:
+        # the search otherwise also times MIOpen's naive reference convolutions — 2.5 s of GPU time per process that can
+        # never win; leaving them out shortens the warm-up (the same kernels get picked).  Set before the first conv.
+        os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
     rank, world, device = D.init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
