@@ -346,3 +346,33 @@ def test_empty_batches_are_no_ops():
     assert tuple(_native.images_to_tensor(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device=d)).shape) == (0, 3, 8, 8)
     assert tuple(_native.tensor_to_images(torch.zeros(0, 3, 8, 8, device=d)).shape) == (0, 8, 8, 3)
     assert tuple(_native.resize_images(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device=d), 4, 4).shape) == (0, 4, 4, 3)
+
+
+def test_upfirdn2d_random_arguments_vs_c_oracle():
+    """Seeded sweep over the whole argument space of the native entry point (asymmetric up/down/pads incl. negative
+    (cropping) pads, 1..5-tap kernels, minor > 1, f32 and f64): every dispatch path vs the C oracle."""
+    from op import _native
+    from oracle import c_oracle
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 60:
+        major, h, w = int(rng.integers(1, 7)), int(rng.integers(1, 80)), int(rng.integers(1, 300))
+        minor = int(rng.choice([1, 1, 1, 2, 3]))
+        kh, kw = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        ux, uy, dx, dy = (int(v) for v in rng.integers(1, 4, 4))
+        pads = tuple(int(v) for v in rng.integers(-2, 5, 4))
+        oh = (h * uy + pads[2] + pads[3] - kh) // dy + 1
+        ow = (w * ux + pads[0] + pads[1] - kw) // dx + 1
+        if oh <= 0 or ow <= 0 or h * uy + pads[2] + pads[3] < kh or w * ux + pads[0] + pads[1] < kw:
+            continue
+        if (min(pads[0], 0) + min(pads[1], 0) + w * ux) <= 0 or (min(pads[2], 0) + min(pads[3], 0) + h * uy) <= 0:
+            continue
+        dt = np.float64 if done % 7 == 0 else np.float32
+        x = rng.standard_normal((major, h, w, minor)).astype(dt)
+        k = rng.standard_normal((kh, kw)).astype(dt)
+        ref = c_oracle.upfirdn2d(x, k, (ux, uy), (dx, dy), pads)
+        y = _native.upfirdn2d(torch.from_numpy(x).to(dev()), torch.from_numpy(k).to(dev()), ux, uy, dx, dy, *pads)
+        tol = 1e-5 if dt == np.float32 else 1e-12
+        np.testing.assert_allclose(y.cpu().numpy(), ref, atol=tol * max(1.0, float(np.abs(ref).max())), rtol=tol,
+                                   err_msg=f'{(major, h, w, minor)} k{kh}x{kw} up{(ux, uy)} down{(dx, dy)} pad{pads}')
+        done += 1
