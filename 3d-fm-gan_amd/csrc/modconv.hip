@@ -167,7 +167,9 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // nothing measurable (+-1 %): the count of A-operand reads is not what limits the MFMA rate.  Not kept.
 // 16-channel chunks for the 64- and 32-channel tiles (twice the MFMAs per pair of barriers): with the same register
 // budgets 28-94 VGPRs spill (1964 vs 1603 us on the 1024^2 layer); with budgets that fit (one block per CU less)
-// 1820 vs 1603 us, 1550 vs 1400 us (512^2), transposed 1033 vs 890 us: co-resident blocks beat longer chunks.  Not kept.)
+// 1820 vs 1603 us, 1550 vs 1400 us (512^2), transposed 1033 vs 890 us: co-resident blocks beat longer chunks.  Not kept.
+// The 128 x 128 tile on 8 waves (512 threads, each wave 64 x 32, 4 waves per SIMD in a 128-register budget): 24 VGPRs
+// spill and it ties with the 4-wave tile (123.6 vs 125.0 TFLOP/s at 64^2).  Not kept.)
 template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) {
   static_assert(!RGB || MODE == 0, "the RGB epilogue belongs to the plain conv");
