@@ -280,3 +280,23 @@ def test_pipelined_forward_matches_serial_for_partial_slices_and_tanh():
         a = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, wrap, tsr_encode='Render Image')
         b = Forward_Inference_3_Encoder(r, r, e_tsr, e_w, e_wp, wrap)            # photo := render for E_Tsr only...
     assert tuple(a.shape) == (3, 3, 32, 32) and not torch.equal(a, b)
+
+
+def test_forward_through_data_parallel_wrappers_equals_bare_modules():
+    """The reference calls Forward_Inference_3_Encoder on DataParallel-wrapped networks (train_3_encoder.py:355-362 —
+    it even requires `.module` on the generator).  Miscellaneous.distributed.data_parallel returns such
+    wrappers; the inference schedule must see through them and give the bare modules' result."""
+    import stylegan2
+    from Miscellaneous import distributed as D
+    from Util.network_util import Forward_Inference_3_Encoder
+    e_tsr, e_w, e_wp = _encoders(8)
+    G = _load(stylegan2.Generator(32, 512, 2), 'generator', 21)
+    p = synth.tensor('dpw/photo', (2, 3, 256, 256), dist='uniform').to(dev())
+    r = synth.tensor('dpw/render', (2, 3, 256, 256), dist='uniform').to(dev())
+    bare = _PinNoise(G)
+    wrapped = [D.data_parallel(m, dev()) for m in (e_tsr, e_w, e_wp)]
+    assert all(hasattr(w, 'module') for w in wrapped)
+    with torch.no_grad():
+        a = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, bare).clone()
+        b = Forward_Inference_3_Encoder(p, r, *wrapped, bare)
+    torch.testing.assert_close(b, a, atol=1e-5 * float(a.abs().max()), rtol=1e-5)
