@@ -10,7 +10,10 @@ Design for xGMI (7 point-to-point links per GPU): the forward path
 runs the whole (photo, render) -> image stack on its own shard of pairs.  Training all-reduces gradients in a few
 large flat buckets (default 256 MiB) instead of the reference's one all_reduce per parameter tensor
 (distributed.py:66-75): E_W_Plus alone is ~1 GB of fp32 gradients in ~300 tensors, and per-link-bound rings want
-few, large messages.
+few, large messages.  gather_grad() offers the library all-reduce, reduce-scatter + all-gather, and a DIRECT form
+(all-to-all of shards + rank-ordered local sum + all-gather) that drives all 7 links of the full mesh at once;
+tools/allreduce_bw.py measures their bus bandwidth against 7 x per-link.  No scaling curve has been measured yet: no
+multi-GPU node was available to this build (rehearsals are gloo on CPU / one shared GPU).
 """
 import os
 import pickle
@@ -75,21 +78,78 @@ def reduce_sum(tensor):
     return tensor
 
 
-def gather_grad(params, bucket_bytes=256 << 20):
-    """Average gradients over ranks: all_reduce(SUM) then / world (distributed.py:66-75), bucketed into flat buffers."""
+GRAD_ALGORITHMS = ('all_reduce', 'reduce_scatter', 'direct')
+
+
+def _reduce_flat(flat, world, algorithm):
+    """SUM over ranks then / world of one flat fp32 bucket whose length is a multiple of `world`, in place.
+
+      all_reduce      one library all-reduce (RCCL picks ring / tree: on the 8-GPU xGMI mesh a ring moves 2*(7/8)*S per
+                      GPU over ONE link direction).
+      reduce_scatter  reduce_scatter_tensor + all_gather_into_tensor: the two halves of the all-reduce as separate
+                      collectives, each rank owning 1/world of the bucket in between (the division happens on the
+                      owned shard only: 1/world of the elementwise work).
+      direct          the fully-connected mesh used as such: all_to_all of the world shards (every GPU sends S/world to
+                      each peer over its own link, all 7 links busy at once), a local sum of the received shards in
+                      RANK ORDER (bit-identical on every rank and from run to run, which ring orders are not), then
+                      all_gather_into_tensor.  2*(S/world) per link and phase instead of the ring's 2*(7/8)*S.
+    """
+    if algorithm == 'all_reduce':
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        return
+    n = flat.numel() // world
+    if algorithm == 'reduce_scatter':
+        shard = torch.empty(n, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+    elif algorithm == 'direct':
+        recv = torch.empty_like(flat)
+        dist.all_to_all_single(recv, flat)
+        shard = recv.view(world, n).sum(0)          # rank order: deterministic association
+    else:
+        raise ValueError(f'gather_grad: algorithm must be one of {GRAD_ALGORITHMS}')
+    shard.div_(world)
+    dist.all_gather_into_tensor(flat, shard)
+
+
+def gather_grad(params, bucket_bytes=256 << 20, algorithm='reduce_scatter'):
+    """Average gradients over ranks: SUM then / world — the arithmetic of the reference's gather_grad
+    (distributed.py:66-75, one all_reduce per parameter tensor), bucketed into flat buffers of `bucket_bytes`.
+
+    Every rank must bring the same buckets: a parameter that has a gradient on SOME rank but not on this one (its
+    branch was not taken here) contributes zeros; a parameter without a gradient on every rank (the mapping network
+    under input_is_latent=True) is skipped everywhere and stays `None`, as in the reference."""
     world = get_world_size()
     if world == 1:
         return
-    grads = [p.grad.data for p in params if p.grad is not None]
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    dev = params[0].device
+    has = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=dev)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX)
+    grads = []
+    for p, h in zip(params, has.tolist()):
+        if not h:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        grads.append(p.grad.data)
     bucket, size = [], 0
 
     def flush():
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
+        total = sum(g.numel() for g in bucket)
+        padded = (total + world - 1) // world * world
+        flat = torch.zeros(padded, dtype=bucket[0].dtype, device=bucket[0].device)
+        off = 0
+        for g in bucket:
+            n = g.numel()
+            flat[off:off + n].copy_(g.reshape(-1))
+            off += n
+        _reduce_flat(flat, world, algorithm)
         off = 0
         for g in bucket:
             n = g.numel()
@@ -160,7 +220,9 @@ def data_parallel(module, device=None, overlap=True, find_unused_parameters=True
         relayout()
     if _active() and get_world_size() > 1 and overlap and any(p.requires_grad for p in module.parameters()):
         ids = [device.index] if (device is not None and device.type == 'cuda') else None
+        # broadcast_buffers=False: the only buffers are the encoders' BatchNorm statistics (eval mode, never updated,
+        # SURVEY F13), the fixed noise maps and FIR taps — identical on every rank by construction
         return nn.parallel.DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=256,
-                                                   gradient_as_bucket_view=True,
+                                                   gradient_as_bucket_view=True, broadcast_buffers=False,
                                                    find_unused_parameters=find_unused_parameters)
     return Replica(module)

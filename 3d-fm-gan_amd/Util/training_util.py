@@ -46,3 +46,21 @@ def g_path_regularize(fake_img, latents, mean_path_length, decay=0.01, probe=Non
 def L1_Loss(output_tensor, target_tensor):
     """Mean absolute error between two image batches in [-1, 1] (training_util.py:103-113)."""
     return torch.mean(torch.abs(output_tensor - target_tensor))
+
+
+def requires_grad(model, flag=True):
+    """Freeze / unfreeze every parameter of a network (train_3_encoder.py:188-190)."""
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def accumulate(model1, model2, decay=0.999):
+    """EMA of the generator weights: model1 <- decay * model1 + (1 - decay) * model2, parameter by parameter
+    (train_3_encoder.py:195-200; the reference writes through `.data`, which is also safe here: no module of this
+    build keeps a derived copy of a weight across forwards, see op/live_weights.py).  Buffers (the fixed noise maps)
+    are not averaged, exactly as in the reference."""
+    par1 = dict(model1.named_parameters())
+    par2 = dict(model2.named_parameters())
+    with torch.no_grad():
+        for k in par1.keys():
+            par1[k].mul_(decay).add_(par2[k].detach(), alpha=1 - decay)

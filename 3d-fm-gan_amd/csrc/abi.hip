@@ -2,6 +2,7 @@
 #include "common.h"
 
 extern "C" int fmgan_abi_version(void) { return FMGAN_ABI_VERSION; }
+extern "C" int fmgan_refresh_entry_bytes(void) { return (int)sizeof(fmgan_refresh_entry); }
 
 extern "C" const char* fmgan_status_string(int status) {
   switch (status) {

@@ -62,6 +62,9 @@ def lib():
     _sig(L.fmgan_resize_bilinear_u8, [vp] * 4 + [i] * 5 + [f, f, vp])
     _sig(L.fmgan_tensor_to_images, [vp, vp, i, i, i, f, f, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
+    _sig(L.fmgan_refresh_entry_bytes, [])
+    _sig(L.fmgan_weight_refresh_blocks, [i, i, i, i, ll], ll)
+    _sig(L.fmgan_weight_refresh_f32, [vp, i, ll, vp])
     if L.fmgan_abi_version() != 1:
         raise RuntimeError('libfmgan_hip.so ABI version mismatch')
     _lib = L

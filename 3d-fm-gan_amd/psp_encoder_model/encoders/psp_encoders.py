@@ -18,6 +18,7 @@ from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
 from .helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
 from stylegan2 import EqualLinear
 from op import fused_leaky_relu
+from op.live_weights import LiveWeights
 from Util.streams import overlap_ok, run_deferred, side_streams
 
 # Inference: the style heads are independent of each other and each ends in a tail of tiny launches (conv at 16^2 ... 1^2
@@ -80,6 +81,7 @@ class GradualStyleEncoder(Module):
         self.latlayer2 = nn.Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
         self.channels_last = True     # GPU only; set False to keep NCHW activations
         self._cl_key = None
+        self._live_weights = None
 
     def _to_channels_last(self):
         """Re-lay the conv weights as NHWC once per (device, parameter storage); values and shapes are untouched."""
@@ -102,6 +104,15 @@ class GradualStyleEncoder(Module):
         return torch.stack([t for _, t in heads], dim=1)
 
     def forward_deferred(self, x):
+        if (not torch.is_grad_enabled()) and x.is_cuda:
+            # the heads' EqualLinear weight*scale / bias*lr_mul: one refresh launch from the live parameters
+            if self._live_weights is None:
+                self._live_weights = LiveWeights(self)
+            with self._live_weights.fresh():
+                return self._forward_deferred(x)
+        return self._forward_deferred(x)
+
+    def _forward_deferred(self, x):
         """The n_styles latents [B,512] as a list of (wait, tensor): call wait() before the current stream reads the
         tensor.  In inference on the GPU the heads run on side streams and wait() is a per-head event, so a consumer
         that needs the latents one layer at a time (the synthesis network) starts while later heads are still running;

@@ -19,6 +19,7 @@ from torch.nn import functional as F
 
 from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from op import _native, modconv
+from op.live_weights import LiveWeights, live
 from Util.streams import side_streams, run_on, overlap_ok
 
 _SQRT2 = math.sqrt(2.0)
@@ -119,19 +120,19 @@ class EqualLinear(nn.Module):
         self.activation = activation
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
-        self._scaled = None   # inference: (parameter versions) -> (weight * scale, bias * lr_mul)
+        self._live = None     # set by op.live_weights.LiveWeights of the enclosing network
 
     def _scaled_params(self):
-        """weight*scale and bias*lr_mul.  With autograd on they are recomputed (they must stay in the graph); under
-        no_grad they are cached until a parameter changes — the reference re-multiplies every 512x512 modulation
-        matrix on every call, 88 elementwise launches per 1024^2 forward for values that never change."""
+        """weight*scale and bias*lr_mul (stylegan2.py:165-175).  Inside the inference forward of a network that owns a
+        LiveWeights table they were re-derived from the live parameters by that forward's single refresh launch (the
+        reference re-multiplies every 512x512 modulation matrix on every call: 88 elementwise launches per 1024^2
+        forward); anywhere else they are computed here.  Nothing survives a forward, so in-place `.data` updates
+        (EMA accumulate, train_3_encoder.py:195-200) can never be missed."""
+        lv = live(self)
+        if lv is not None:
+            return lv
         w, b = self.weight, self.bias
-        if torch.is_grad_enabled():
-            return w * self.scale, (None if b is None else b * self.lr_mul)
-        key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
-        if self._scaled is None or self._scaled[0] != key:
-            self._scaled = (key, (w * self.scale).detach(), None if b is None else (b * self.lr_mul).detach())
-        return self._scaled[1], self._scaled[2]
+        return w * self.scale, (None if b is None else b * self.lr_mul)
 
     def forward(self, input):
         weight, bias = self._scaled_params()
@@ -187,30 +188,27 @@ class ModulatedConv2d(nn.Module):
         self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
-        self._wt = None  # (weight version, data_ptr, device) -> MFMA-layout copy of scale*weight
-        self._wsq = None  # same key -> per-(o,i) sum of squared taps (demodulation)
+        self._live = None     # set by op.live_weights.LiveWeights of the enclosing network
 
     def __repr__(self):
         return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
                 f'upsample={self.upsample}, downsample={self.downsample})')
 
     def mfma_weight(self):
-        """wt[i][tap][o] = scale * weight[o][i][tap], rebuilt only when the parameter changed."""
-        w = self.weight
-        key = (w._version, w.data_ptr(), w.device)
-        if self._wt is None or self._wt[0] != key:
-            with torch.no_grad():
-                self._wt = (key, _native.modconv_weight_prep(w.detach(), self.scale))
-        return self._wt[1]
+        """wt[i][tap][o] = scale * weight[o][i][tap]: this forward's refreshed table entry, else derived now."""
+        lv = live(self)
+        if lv is not None:
+            return lv[0]
+        with torch.no_grad():
+            return _native.modconv_weight_prep(self.weight.detach(), self.scale)
 
     def mfma_wsq(self):
-        """Per-(o,i) sum of squared taps for the demodulation kernel, rebuilt only when the parameter changed."""
-        w = self.weight
-        key = (w._version, w.data_ptr(), w.device)
-        if self._wsq is None or self._wsq[0] != key:
-            with torch.no_grad():
-                self._wsq = (key, _native.modconv_wsq(w.detach()))
-        return self._wsq[1]
+        """Per-(o,i) sum of squared taps for the demodulation kernel (same rule as mfma_weight)."""
+        lv = live(self)
+        if lv is not None:
+            return lv[1]
+        with torch.no_grad():
+            return _native.modconv_wsq(self.weight.detach())
 
     def styles(self, style):
         return self.modulation(style)
@@ -277,7 +275,9 @@ class StyledConv(nn.Module):
     def _fused(self, input, style, noise):
         conv, act = self.conv, self.activate
         s = conv.styles(style)
-        demod = _native.modconv_demod(conv.weight, s, conv.scale, conv.eps, conv.mfma_wsq()) if conv.demodulate else None
+        lv = live(conv)     # (wt, wsq) refreshed by the enclosing network's forward, if any
+        demod = (_native.modconv_demod(conv.weight, s, conv.scale, conv.eps, lv[1] if lv else None)
+                 if conv.demodulate else None)
         b, _, h, w = input.shape
         oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
         if noise is None:
@@ -315,7 +315,9 @@ class StyledConv(nn.Module):
         """StyledConv + ToRGB in one kernel (inference): returns (activation or None, rgb)."""
         conv, act = self.conv, self.activate
         s = conv.styles(style)
-        demod = _native.modconv_demod(conv.weight, s, conv.scale, conv.eps, conv.mfma_wsq()) if conv.demodulate else None
+        lv = live(conv)     # (wt, wsq) refreshed by the enclosing network's forward, if any
+        demod = (_native.modconv_demod(conv.weight, s, conv.scale, conv.eps, lv[1] if lv else None)
+                 if conv.demodulate else None)
         if noise is None:
             noise = input.new_empty(input.shape[0], 1, input.shape[2], input.shape[3]).normal_()
         return _native.modconv2d_rgb(input, conv.mfma_weight(), s, demod, noise, self.noise.weight, act.bias,
@@ -365,10 +367,9 @@ class _LatentColumns:
         self.provider, self.n = provider, n_latent
 
     def __getitem__(self, idx):
-        col = idx[1]
-        if not (isinstance(idx, tuple) and isinstance(col, int) and idx[0] == slice(None)):
+        if not (isinstance(idx, tuple) and len(idx) == 2 and isinstance(idx[1], int) and idx[0] == slice(None)):
             raise IndexError('only latent[:, i] is served column-wise')
-        return self.provider(col)
+        return self.provider(idx[1])
 
 
 class Generator(nn.Module):
@@ -415,6 +416,7 @@ class Generator(nn.Module):
             self.convs.append(StyledConv(c_in, c_mid, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
             self.convs.append(StyledConv(c_mid, c_out, 3, style_dim, blur_kernel=blur_kernel))
             self.to_rgbs.append(ToRGB(c_out, style_dim))
+        self._live_weights = None
 
     def make_noise(self):
         device = self.input.input.device
@@ -441,10 +443,21 @@ class Generator(nn.Module):
         second = styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)
         return torch.cat([first, second], 1)
 
-    def forward(self, noise_z, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
-                latent_styles=None, input_is_latent=False, noise=None, randomize_noise=True,
-                use_external_input_tensor=False, external_input_tensor=None, PPL_regularize=False,
-                return_rgb_list=False, return_style_scalars=False, latent_columns=None):
+    def forward(self, *args, **kwargs):
+        """Generator.forward of the reference (stylegan2.py:554-688; signature: _forward).  An inference call on the GPU
+        first re-derives every scaled / MFMA-layout weight of the network from the live parameters in one launch
+        (op/live_weights.py) and then runs the layers on those buffers."""
+        if (not torch.is_grad_enabled()) and self.input.input.is_cuda:
+            if self._live_weights is None:
+                self._live_weights = LiveWeights(self)
+            with self._live_weights.fresh():
+                return self._forward(*args, **kwargs)
+        return self._forward(*args, **kwargs)
+
+    def _forward(self, noise_z, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                 latent_styles=None, input_is_latent=False, noise=None, randomize_noise=True,
+                 use_external_input_tensor=False, external_input_tensor=None, PPL_regularize=False,
+                 return_rgb_list=False, return_style_scalars=False, latent_columns=None):
         """latent_columns (not in the reference): callable i -> W+[:, i] replacing latent_styles; inference only, with
         an external input tensor (see _LatentColumns)."""
         if latent_columns is not None:

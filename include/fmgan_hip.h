@@ -55,7 +55,7 @@ const char *fmgan_status_string(int status);
 
 /* Which upfirdn2d kernel `fmgan_upfirdn2d` would pick for these arguments:
  * 0 generic, 1 row-march (up=down=1, wide rows), 2 LDS plane-tile (up=down=1,
- * small planes), 3 up=2 polyphase, 5 down=2.  Pure host logic, no GPU needed.
+ * small planes), 3 up=2 polyphase.  Pure host logic, no GPU needed.
  * `force_path` in fmgan_upfirdn2d uses the same numbering (-1 = automatic). */
 int fmgan_upfirdn2d_select(int dtype, int major, int in_h, int in_w, int minor,
                            int kernel_h, int kernel_w, int up_x, int up_y,
@@ -168,10 +168,37 @@ int fmgan_modconv_demod_wsq_f32(const float *wsq, const float *style, float *dem
  *   kind 0  wt[i][tap][o] = scale * weight[o][i][tap]            forward (modes 0, 1, and the downsample branch, mode 2)
  *   kind 1  wt[o][tap][i] = scale * weight[o][i][ktaps-1-tap]    data-gradient of the plain conv    (run as mode 0)
  *   kind 2  wt[o][tap][i] = scale * weight[o][i][tap]            data-gradient of the transposed conv (run as mode 2)
- * Depends on the parameter only — the host shim caches it per parameter version.
+ * Depends on the parameter only.  The host shim never caches it across forwards (in-place parameter updates
+ * through `.data` give no invalidation signal): inference re-derives every layer's table with fmgan_weight_refresh_f32.
  */
 int fmgan_modconv_weight_prep_f32(const float *weight, float *wt, int cout, int cin, int ktaps,
                                   float scale, int kind, void *stream);
+
+/*
+ * All derived weights of a network, re-derived from the live parameters in ONE launch per inference forward
+ * (replaces the per-call `weight * scale` / `bias * lr_mul` of every EqualLinear, stylegan2.py:165-175, and the
+ * per-call weight preparation of every ModulatedConv2d, stylegan2.py:257-262; nothing is cached across forwards, so
+ * the reference's in-place EMA update `accumulate`, train_3_encoder.py:195-200, needs no invalidation hook).
+ *   table_dev: DEVICE array of n_entries entries, sorted by block_begin (entry k owns logical blocks
+ *              [block_begin_k, block_begin_k + fmgan_weight_refresh_blocks(entry k)) ); total_blocks = their sum.
+ *   kind 0: dst[k] = src[k] * scale, k < n
+ *   kind 1: dst = wt[i][tap][o] = scale * src[o][i][tap] (layout kind 0 of fmgan_modconv_weight_prep_f32), and, if
+ *           dst2 != NULL, dst2 = wsq[o][i] = sum_tap src[o][i][tap]^2 (fmgan_modconv_wsq_f32); ktaps <= 9.
+ * Bit-identical to the separate kernels (same operations in the same order).
+ */
+typedef struct fmgan_refresh_entry {
+  const void *src;
+  void *dst;
+  void *dst2;
+  long long n;            /* kind 0: element count */
+  int kind, cout, cin, ktaps;
+  float scale;
+  unsigned block_begin;
+} fmgan_refresh_entry;
+int fmgan_refresh_entry_bytes(void);      /* sizeof(fmgan_refresh_entry), for bindings that build the table by hand */
+long long fmgan_weight_refresh_blocks(int kind, int cout, int cin, int ktaps, long long n);
+int fmgan_weight_refresh_f32(const fmgan_refresh_entry *table_dev, int n_entries, long long total_blocks,
+                             void *stream);
 
 /*
  * Modulated 3x3 convolution, input-modulated form with batch-shared weights

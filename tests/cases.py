@@ -129,6 +129,27 @@ E2E_CASES = [
     dict(name='e2e_1024', size=1024, b=1, tsr_encode='Photo Image', sliced_layer=None, use_tanh=False, stride=32),
 ]
 
+# BASELINE config 3 (full 3-encoder forward + backward @256^2): L1 loss to a synthetic target, gradients of EVERY
+# trainable parameter of E_Tsr / E_W / E_W_Plus / G, stored as a strided sample + the L2 norm of each tensor.
+E2E_GRAD_CASE = dict(name='e2e_256_grad', size=256, b=2, tsr_encode='Photo Image', sliced_layer=None, use_tanh=False,
+                     stride=8)
+GRAD_SAMPLES = 48
+
+
+def grad_sample(t):
+    """(strided sample of <= GRAD_SAMPLES elements, L2 norm in float64) of a gradient tensor."""
+    flat = t.detach().reshape(-1)
+    step = max(1, flat.numel() // GRAD_SAMPLES)
+    return flat[::step][:GRAD_SAMPLES].cpu().numpy(), float(flat.double().pow(2).sum().sqrt())
+
+
+# One training iteration's four gradient computations (train_3_encoder.py:448-596) at a size the CPU reference
+# finishes in a minute: Generator(64) + Discriminator(64), encoders on 256^2 (they are shape-locked to it, SURVEY F5).
+TRAIN_STEP_CASE = dict(name='train_64', size=64, b=4, ppl_idx=[0, 2])
+# train_3_encoder_hyperparams.py:53-63
+TRAIN_HP = dict(lr=0.001, r1=10, d_reg_every=16, g_reg_every=4, path_reg_weight=2, path_reg_batch_shrink=2,
+                l1_loss_lambda=3)
+
 DISCRIMINATOR_CASES = [
     dict(name='d64', size=64, b=4),
     dict(name='d256', size=256, b=2),

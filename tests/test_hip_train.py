@@ -1,0 +1,352 @@
+"""GPU parity of the TRAINING side of the hot path against fixtures generated from the imported reference
+(tools/make_golden.py: gen_e2e_grad, gen_train_step):
+
+  * BASELINE config 3 — full 3-encoder forward + backward @256^2 through the data_parallel wrappers: every parameter
+    gradient of E_Tsr / E_W / E_W_Plus / G vs the reference's, judged against the reference's own fp64 run;
+  * the four gradient computations of one training iteration (D loss, R1, G loss, path length) of train_3_encoder.py
+    (this build: 3d-fm-gan_amd/train_3_encoder.py) vs the reference modules + the reference's loss functions;
+  * a world-size-2 run (two processes on this GPU, gloo) of those phases == the single-process run on the
+    concatenated batch, for DDP and for each explicit gather_grad algorithm.
+
+Tolerance rule for gradients.  The reference's fp32 CPU gradients themselves differ from its fp64 gradients by up to
+~1e-2 of a tensor's max (L1's sign(), long reductions), so a fixed relative tolerance vs the fp32 fixture would be
+either vacuous or flaky.  Each tensor is therefore held to
+      |hip - fp64|  <=  MARGIN * |ref_fp32 - fp64|  +  FLOOR * max|fp64|
+i.e. "no farther from the exact value than the reference itself, up to a small factor"; the measured ratios are
+printed by tools/measure_parity.py and quoted in DESIGN.md §0.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MARGIN, FLOOR = 4.0, 2e-4
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def _load(module, kind, seed):
+    module.load_state_dict(synth.state_dict(kind, module.state_dict(), seed=seed))
+    return module.to(dev()).eval()
+
+
+def build_nets(size, with_d=False, n_mlp=8):
+    import stylegan2
+    import resnet_encoder
+    from psp_encoder_model.encoders import psp_encoders
+    n_latent = int(np.log2(size)) * 2 - 2
+    nets = dict(
+        e_tsr=_load(resnet_encoder.resnet18(tensor_encoding=True, tensor_transform=False), 'resnet', 5),
+        e_w=_load(resnet_encoder.resnet18(tensor_encoding=False, tensor_transform=False), 'resnet', 6),
+        e_wp=_load(psp_encoders.GradualStyleEncoder(18, 'ir_se', types.SimpleNamespace(input_nc=3, n_styles=n_latent)),
+                   'psp', 7),
+        g=_load(stylegan2.Generator(size, 512, n_mlp), 'generator', 4))
+    if with_d:
+        nets['d'] = _load(stylegan2.Discriminator(size), 'discriminator', 8)
+    return nets
+
+
+class PinNoise(torch.nn.Module):
+    """Forward_Inference_3_Encoder never passes noise; the fixtures pinned randomize_noise=False.
+    `.module` is what the reference reads n_latent from (Util/network_util.py:317-318)."""
+
+    def __init__(self, g, call=None):
+        super().__init__()
+        self.module = g
+        self._call = [call if call is not None else g]      # in a list: not a registered submodule twice
+
+    def forward(self, **kw):
+        return self._call[0](randomize_noise=False, **kw)
+
+
+def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=FLOOR):
+    """Every parameter gradient vs the fixture (strided sample + norm) under the rule in the module docstring."""
+    n = 0
+    worst = 0.0
+    for name, p in named_params:
+        key = f'{prefix}/{name}'
+        if key + '/s' not in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f'{key}: reference has no gradient here'
+            continue
+        assert p.grad is not None, f'{key}: no gradient'
+        s, nrm = cases.grad_sample(p.grad)
+        s64, n64 = g[key + '/s64'], float(g[key + '/n64'])
+        s32, n32 = g[key + '/s'], float(g[key + '/n'])
+        scale = max(float(np.abs(s64).max()), 1e-30)
+        e_hip = float(np.abs(s - s64).max()) / scale
+        e_ref = float(np.abs(s32 - s64).max()) / scale
+        en_hip, en_ref = abs(nrm - n64) / max(n64, 1e-30), abs(n32 - n64) / max(n64, 1e-30)
+        if report is not None:
+            report.append((key, e_hip, e_ref, en_hip, en_ref))
+        assert e_hip <= margin * e_ref + floor, f'{key}: sample err {e_hip:.3e} vs reference-fp32 err {e_ref:.3e}'
+        assert en_hip <= margin * en_ref + floor, f'{key}: norm err {en_hip:.3e} vs reference-fp32 err {en_ref:.3e}'
+        worst = max(worst, e_hip)
+        n += 1
+    return n, worst
+
+
+def run_e2e_grad(report=None):
+    from Miscellaneous import distributed as D
+    from Util.network_util import Forward_Inference_3_Encoder
+    from Util.training_util import L1_Loss
+    c = cases.E2E_GRAD_CASE
+    nets = build_nets(c['size'])
+    for m in nets.values():
+        m.requires_grad_(True)
+    wrapped = {k: D.data_parallel(m, dev()) for k, m in nets.items()}
+    assert all(hasattr(w, 'module') for w in wrapped.values())
+    p = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform').to(dev())
+    r = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform').to(dev())
+    target = synth.tensor(c['name'] + '/target', (c['b'], 3, c['size'], c['size']), dist='uniform').to(dev())
+    img = Forward_Inference_3_Encoder(p, r, wrapped['e_tsr'], wrapped['e_w'], wrapped['e_wp'],
+                                      PinNoise(nets['g'], wrapped['g']), tsr_encode=c['tsr_encode'],
+                                      sliced_layer=c['sliced_layer'], use_tanh=c['use_tanh'])
+    loss = L1_Loss(img, target)
+    loss.backward()
+    return nets, img, loss
+
+
+def test_cfg3_forward_backward_golden(golden):
+    """BASELINE config 3: (photo, render) -> image -> L1 -> backward through G and the three encoders, called through
+    Miscellaneous.distributed.data_parallel wrappers (train_3_encoder.py:495-558 with the L1 term)."""
+    g = golden('e2e_grad')
+    nets, img, loss = run_e2e_grad()
+    c = cases.E2E_GRAD_CASE
+    a = img.detach().cpu().numpy()[..., ::c['stride'], ::c['stride']]
+    ref64 = g['img/sub64']
+    scale = float(np.abs(ref64).max())
+    e_hip, e_ref = np.abs(a - ref64).max() / scale, np.abs(g['img/sub'] - ref64).max() / scale
+    assert e_hip <= MARGIN * e_ref + 2e-5, (e_hip, e_ref)
+    np.testing.assert_allclose(loss.item(), float(g['loss64']), rtol=2e-5)
+    total = 0
+    for k, m in nets.items():
+        n, _ = check_grads(g, k, m.named_parameters())
+        total += n
+    assert total == len([k for k in g.files if k.endswith('/n64')])     # every fixture tensor was compared
+    assert nets['g'].style[1].weight.grad is None                       # mapping network unused (input_is_latent)
+
+
+class FixedProbe:
+    """Generator.forward draws the path-length probe with torch.randn_like (stylegan2.py:684); the fixture pinned it."""
+
+    def __init__(self, probe):
+        self.probe = probe
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+        torch.randn_like = lambda t, **kw: self.probe.to(dtype=t.dtype, device=t.device)
+
+    def __exit__(self, *exc):
+        torch.randn_like = self.orig
+
+
+def train_args(**over):
+    import train_3_encoder as T
+    hp = cases.TRAIN_HP
+    return T.default_args(tsr_encode='Photo Image', lr=hp['lr'], r1=hp['r1'], d_reg_every=hp['d_reg_every'],
+                          g_reg_every=hp['g_reg_every'], generator_path_reg_weight=hp['path_reg_weight'],
+                          path_reg_batch_shrink=hp['path_reg_batch_shrink'], l1_loss_lambda=hp['l1_loss_lambda'],
+                          **over)
+
+
+def train_inputs(lo=None, hi=None):
+    c = cases.TRAIN_STEP_CASE
+    photo = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform')
+    render = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform')
+    ref = synth.tensor(c['name'] + '/ref', (c['b'], 3, c['size'], c['size']), dist='uniform')
+    probe = synth.tensor(c['name'] + '/probe', (len(c['ppl_idx']), 3, c['size'], c['size']))
+    return tuple(t.to(dev()) for t in (photo, render, ref, probe))
+
+
+def run_phase(phase, nets, args, photo, render, ref, probe, ppl_idx):
+    """One of the four gradient computations, no optimiser step; returns the loss dict."""
+    import train_3_encoder as T
+    G = PinNoise(nets['g'].module if hasattr(nets['g'], 'module') else nets['g'], nets['g'])
+    ld = {}
+    if phase == 'd':
+        T.D_Loss_BackProp(G, nets['e_tsr'], nets['e_w'], nets['e_wp'], nets['d'], photo, render, ref, args, ld, None)
+    elif phase == 'r1':
+        ld['r1'] = T.D_Reg_BackProp(ref, nets['d'], args, None)
+    elif phase == 'g':
+        T.G_Loss_BackProp(G, nets['e_tsr'], nets['e_w'], nets['e_wp'], nets['d'], photo, render, ref, args, ld, None)
+    else:
+        with FixedProbe(probe):
+            ld['ppl'], ld['lengths'], _ = T.G_Reg_BackProp(G, nets['e_tsr'], nets['e_w'], nets['e_wp'], photo, render,
+                                                           args, 0, None, choice=ppl_idx)
+    return ld
+
+
+@pytest.mark.parametrize('phase', ['d', 'r1', 'g', 'ppl'])
+def test_train_step_phase_golden(phase, golden):
+    """D_Loss_BackProp / D_Reg_BackProp / G_Loss_BackProp / G_Reg_BackProp vs the reference modules and the reference's
+    loss functions at the same weights (train_3_encoder.py:448-596)."""
+    g = golden('train_step')
+    c = cases.TRAIN_STEP_CASE
+    nets = build_nets(c['size'], with_d=True, n_mlp=2)
+    photo, render, ref, probe = train_inputs()
+    ld = run_phase(phase, nets, train_args(), photo, render, ref, probe, c['ppl_idx'])
+    if phase == 'd':
+        np.testing.assert_allclose(ld['d'].item(), float(g['d/loss64']), rtol=1e-4)
+        np.testing.assert_allclose(ld['ref_score'].item(), float(g['d/ref_score64']), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ld['out_score'].item(), float(g['d/out_score64']), rtol=1e-4, atol=1e-5)
+        n, _ = check_grads(g, 'd/d', nets['d'].named_parameters())
+        assert n > 30
+        assert all(p.grad is None for p in nets['g'].parameters())       # producers frozen
+    elif phase == 'r1':
+        np.testing.assert_allclose(ld['r1'].item(), float(g['r1/loss64']), rtol=1e-3)
+        n, _ = check_grads(g, 'r1/d', nets['d'].named_parameters(), margin=6.0, floor=5e-4)
+        assert n > 30
+    elif phase == 'g':
+        np.testing.assert_allclose(ld['g'].item(), float(g['g/loss64']), rtol=1e-4)
+        np.testing.assert_allclose(ld['l1'].item(), float(g['g/l164']), rtol=1e-4)
+        for k in ('g', 'e_tsr', 'e_w', 'e_wp'):
+            n, _ = check_grads(g, 'g/' + k, nets[k].named_parameters())
+            assert n > 20
+        assert all(p.grad is None for p in nets['d'].parameters())       # D frozen
+    else:
+        np.testing.assert_allclose(ld['lengths'].detach().cpu().numpy(), g['ppl/lengths64'], rtol=1e-3)
+        np.testing.assert_allclose(ld['ppl'].item(), float(g['ppl/loss64']), rtol=2e-3)
+        for k in ('g', 'e_tsr', 'e_w', 'e_wp'):
+            n, _ = check_grads(g, 'ppl/' + k, nets[k].named_parameters(), margin=6.0, floor=5e-4)
+            assert n > 20
+
+
+def test_trainer_iteration_runs_and_updates_everything():
+    """One Trainer.step (D, R1, G, path length, EMA — train_3_encoder.py:801-822): finite losses, every trained
+    network and g_ema moved, and the next no_grad g_ema forward sees the EMA update."""
+    import train_3_encoder as T
+    c = cases.TRAIN_STEP_CASE
+    nets = build_nets(c['size'], with_d=True, n_mlp=2)
+    photo, render, ref, _ = train_inputs()
+    lat = synth.tensor('tr/lat', (1, nets['g'].n_latent, 512)).to(dev())
+    tsr = synth.tensor('tr/tsr', (1, 512, 4, 4)).to(dev())
+    tr = T.Trainer(dict(G=nets['g'], E_Tsr=nets['e_tsr'], E_W=nets['e_w'], E_W_Plus=nets['e_wp'], D=nets['d']),
+                   train_args(), dev())
+
+    def ema_image():
+        with torch.no_grad():
+            return tr.g_ema(None, latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True,
+                            external_input_tensor=tsr, randomize_noise=False).clone()
+
+    before = {k: [p.detach().clone() for p in m.parameters()] for k, m in nets.items()}
+    img0 = ema_image()
+    ld = tr.step(photo, render, ref)
+    for k in ('d', 'r1', 'g', 'l1', 'g_reg'):
+        assert torch.isfinite(ld[k]).all(), k
+    for k, m in nets.items():
+        moved = sum(int(not torch.equal(a, b)) for a, b in zip(before[k], m.parameters()))
+        assert moved > 0.5 * len(before[k]), f'{k}: {moved} of {len(before[k])} tensors updated'
+    assert not torch.equal(ema_image(), img0)
+    assert tr.iter_idx == 1 and float(tr.mean_path_length) > 0
+    ld = tr.step(photo, render, ref)           # iteration 1: no R1, no path-length step
+    assert torch.isfinite(ld['d']).all() and tr.iter_idx == 2
+
+
+# ----------------------------------------------------------------------------------------------- world size 2
+_WORKER = r'''
+import os, sys, json
+root = sys.argv[1]; mode = sys.argv[2]; out = sys.argv[3]
+for p in (root, os.path.join(root, '3d-fm-gan_amd'), os.path.join(root, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import cases, synth
+from Miscellaneous import distributed as D
+import test_hip_train as H
+rank, world, device = D.init_distributed(backend='gloo')
+assert world == 2
+c = cases.TRAIN_STEP_CASE
+nets = H.build_nets(c['size'], with_d=True, n_mlp=2)
+for m in nets.values():
+    m.requires_grad_(True)
+ddp = mode == 'ddp'
+wrapped = {k: D.data_parallel(m, device, overlap=ddp) for k, m in nets.items()}
+args = H.train_args(grad_sync='ddp' if ddp else 'flat', grad_algorithm=mode if not ddp else 'all_reduce')
+photo, render, ref, probe = H.train_inputs()
+lo, hi = D.shard_range(c['b'])
+res = {}
+for phase in ('d', 'r1', 'g', 'ppl'):
+    for m in nets.values():
+        m.zero_grad(set_to_none=True)
+    # path length: local sample 0 of each rank (global samples 0 and 2, the fixture's choice)
+    H.run_phase(phase, wrapped, args, photo[lo:hi], render[lo:hi], ref[lo:hi], probe[rank:rank + 1], [0])
+    for k, m in nets.items():
+        for name, p in m.named_parameters():
+            if p.grad is not None:
+                s, n = cases.grad_sample(p.grad)
+                res[f'{phase}/{k}/{name}/s'] = s; res[f'{phase}/{k}/{name}/n'] = np.float64(n)
+np.savez(out + f'.{rank}.npz', **res)
+D.synchronize()
+torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('mode', ['ddp', 'direct', 'reduce_scatter'])
+def test_world2_phases_equal_single_process(mode, tmp_path):
+    """Two ranks (two processes sharing this GPU, gloo), each on half of the batch: the rank-averaged gradients of
+    every phase equal the single-process gradients on the whole batch (the reference's DataParallel semantics).
+    D's minibatch-stddev layer groups samples i, i+B/4, ... (stylegan2.py:805-813): the single-process batch is laid
+    out so that its groups are the ranks' groups (DataParallel computes the statistic per replica too)."""
+    import subprocess
+    c = cases.TRAIN_STEP_CASE
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    out = str(tmp_path / 'res')
+    port = 29500 + (os.getpid() % 400) + {'ddp': 0, 'direct': 1, 'reduce_scatter': 2}[mode]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), str(script), ROOT, mode, out]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1400)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert 'Grad strides do not match bucket view strides' not in proc.stderr
+    r0, r1 = np.load(out + '.0.npz'), np.load(out + '.1.npz')
+    # single process on the whole batch; minibatch-stddev groups: rank r's samples at positions r, r+2 (b = 4 -> group
+    # size 4 needs b = 8; with b = 4 per process and 2 per rank the group is min(batch, 4) = the whole local batch)
+    nets = build_nets(c['size'], with_d=True, n_mlp=2)
+    photo, render, ref, probe = train_inputs()
+    args = train_args()
+    checked = 0
+    for phase in ('d', 'r1', 'g', 'ppl'):
+        for m in nets.values():
+            m.zero_grad(set_to_none=True)
+        single_nets = dict(nets)
+        if phase in ('d', 'r1', 'g'):
+            single_nets['d'] = _PerHalfD(nets['d'])
+        run_phase(phase, single_nets, args, photo, render, ref, probe, c['ppl_idx'])
+        for k, m in nets.items():
+            for name, p in m.named_parameters():
+                key = f'{phase}/{k}/{name}'
+                if p.grad is None:
+                    assert key + '/s' not in r0.files
+                    continue
+                s, n = cases.grad_sample(p.grad)
+                np.testing.assert_array_equal(r0[key + '/s'], r1[key + '/s'])       # ranks agree bit for bit
+                scale = max(float(np.abs(s).max()), 1e-30)
+                assert float(np.abs(r0[key + '/s'] - s).max()) <= 2e-3 * scale + 1e-9, key
+                assert abs(float(r0[key + '/n']) - n) <= 2e-3 * n + 1e-9, key
+                checked += 1
+    assert checked > 600
+
+
+class _PerHalfD(torch.nn.Module):
+    """D applied to each rank's half separately: the minibatch-stddev statistic (stylegan2.py:805-813) is per replica in
+    the reference's DataParallel and per rank here; everything else in D is per sample."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.module = d
+
+    def forward(self, x):
+        h = x.shape[0] // 2
+        return torch.cat([self.module(x[:h]), self.module(x[h:])], 0)

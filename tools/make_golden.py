@@ -36,6 +36,12 @@ import resnet_encoder  # noqa: E402
 from psp_encoder_model.encoders import psp_encoders  # noqa: E402
 import Util.network_util as network_util  # noqa: E402
 from op import upfirdn2d as ref_upfirdn2d, fused_leaky_relu as ref_fused_leaky_relu  # noqa: E402
+# Util/training_util.py imports Util.landmark_util, which imports `face_alignment` from a hard-coded home path
+# (train_3_encoder.py:39-41; absent third-party dependency): stubbed like torchvision; none of the loss functions used
+# here touch it.
+_lm = types.ModuleType('Util.landmark_util'); _lm.Get_HeatMap_PyTorch = None
+sys.modules['Util.landmark_util'] = _lm
+import Util.training_util as ref_training_util  # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 torch.set_grad_enabled(True)
@@ -241,11 +247,204 @@ def gen_image_io():
     print('image_io', len(out))
 
 
+def _sample_grads(out, prefix, named_params, suffix=''):
+    """Strided sample + L2 norm of every parameter's .grad (tests/cases.py::grad_sample); unused parameters
+    (grad None: the mapping network and constant input under input_is_latent / external tensor) are recorded as absent."""
+    for name, p in named_params:
+        if p.grad is None:
+            continue
+        s, n = cases.grad_sample(p.grad)
+        out[f'{prefix}/{name}/s{suffix}'] = s
+        out[f'{prefix}/{name}/n{suffix}'] = np.float64(n)
+
+
+def gen_e2e_grad():
+    """BASELINE config 3: (photo, render) -> image -> L1 loss (Util/training_util.py:103-113) -> backward through the
+    Generator and the three encoders (train_3_encoder.py:495-558 with only the L1 term), in fp32 (the reference's
+    precision) and in fp64 (the yardstick both fp32 implementations are measured against)."""
+    c = cases.E2E_GRAD_CASE
+    out = {}
+    n_latent = int(np.log2(c['size'])) * 2 - 2
+    for dt, sfx in ((torch.float32, ''), (torch.float64, '64')):
+        e_tsr, e_w, e_wp = build_encoders(n_latent)
+        g = stylegan2.Generator(c['size'], 512, 8)
+        g.load_state_dict(synth.state_dict('generator', g.state_dict(), seed=4))
+        nets = dict(e_tsr=e_tsr, e_w=e_w, e_wp=e_wp, g=g)
+        for m in nets.values():
+            m.to(dt)
+        g.eval()
+        p = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform').to(dt)
+        r = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform').to(dt)
+        target = synth.tensor(c['name'] + '/target', (c['b'], 3, c['size'], c['size']), dist='uniform').to(dt)
+        img = network_util.Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, _GWrap(g), tsr_encode=c['tsr_encode'],
+                                                       sliced_layer=c['sliced_layer'], use_tanh=c['use_tanh'])
+        loss = ref_training_util.L1_Loss(img, target)
+        loss.backward()
+        out['img/sub' + sfx] = subsample(img, c['stride'])
+        out['loss' + sfx] = np.float64(loss.item())
+        for k, m in nets.items():
+            _sample_grads(out, k, m.named_parameters(), sfx)
+        print('  e2e_grad', dt, loss.item())
+    np.savez_compressed(os.path.join(OUT, 'e2e_grad.npz'), **out)
+    print('e2e_grad', len(out))
+
+
+def gen_fp64():
+    """The reference modules in float64 on the same inputs/weights: the yardstick for 'how far is an fp32 result from
+    the exact value'.  tests compare |HIP - fp64| with |reference fp32 (the golden files above) - fp64|."""
+    out = {}
+    with torch.no_grad():
+        for c in cases.GENERATOR_CASES:
+            if c['mode'] != 'latent':
+                continue
+            g = stylegan2.Generator(c['size'], 512, c['n_mlp'], generator_net_shape=c['shape'])
+            g.load_state_dict(synth.state_dict('generator', g.state_dict(), seed=4))
+            g.double().eval()
+            cin0 = c['shape'][0] if c['shape'] else 512
+            lat = synth.tensor(c['name'] + '/latent', (c['b'], g.n_latent, 512)).double()
+            tsr = synth.tensor(c['name'] + '/tsr', (c['b'], cin0, 4, 4)).double()
+            img = g(None, latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True,
+                    external_input_tensor=tsr, randomize_noise=False)
+            out[c['name'] + '/sub'] = subsample(img, c['stride'])
+            print(' ', c['name'])
+        for c in cases.E2E_CASES:
+            n_latent = int(np.log2(c['size'])) * 2 - 2
+            e_tsr, e_w, e_wp = build_encoders(n_latent)
+            for m in (e_tsr, e_w, e_wp):
+                m.double()
+            p = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform').double()
+            r = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform').double()
+            out[c['name'] + '/e_tsr'] = npy(e_tsr(p))
+            out[c['name'] + '/e_w'] = npy(e_w(r))
+            out[c['name'] + '/e_wplus'] = npy(e_wp(p))
+            g = stylegan2.Generator(c['size'], 512, 8)
+            g.load_state_dict(synth.state_dict('generator', g.state_dict(), seed=4))
+            g.double().eval()
+            img = network_util.Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, _GWrap(g), tsr_encode=c['tsr_encode'],
+                                                           sliced_layer=c['sliced_layer'], use_tanh=c['use_tanh'])
+            out[c['name'] + '/sub'] = subsample(img, c['stride'])
+            print(' ', c['name'])
+        for c in cases.DISCRIMINATOR_CASES:
+            d = stylegan2.Discriminator(c['size'])
+            d.load_state_dict(synth.state_dict('discriminator', d.state_dict(), seed=8))
+            d.double()
+            x = synth.tensor(c['name'] + '/x', (c['b'], 3, c['size'], c['size']), dist='uniform').double()
+            out[c['name'] + '/out'] = npy(d(x))
+            print(' ', c['name'])
+    np.savez_compressed(os.path.join(OUT, 'fp64.npz'), **out)
+    print('fp64', len(out))
+
+
+class _FixedProbe:
+    """Generator.forward draws its path-length probe with torch.randn_like (stylegan2.py:684); pin it to a synth tensor
+    for the duration of one call so both sides use the same probe."""
+
+    def __init__(self, probe):
+        self.probe = probe
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+        torch.randn_like = lambda t, **kw: self.probe.to(dtype=t.dtype, device=t.device)
+
+    def __exit__(self, *exc):
+        torch.randn_like = self.orig
+
+
+def gen_train_step():
+    """The four gradient computations of one training iteration (train_3_encoder.py:448-596) with the reference's
+    modules and the reference's own loss functions (Util/training_util.py), all evaluated at the same weights:
+      d:   D_Loss_BackProp   d_logistic_loss(D(ref), D(fake)),  fake from frozen G/encoders           (:448-477)
+      r1:  D_Reg_BackProp    r1/2 * d_r1_loss * d_reg_every + 0 * real_pred[0]                        (:479-493)
+      g:   G_Loss_BackProp   g_nonsaturating_loss(D(fake)) + l1_lambda * L1_Loss  (LPIPS / ArcFace / landmark terms
+           need pretrained third-party weights that are not available offline)             (:495-558)
+      ppl: G_Reg_BackProp    path-length penalty on batch/2 through PPL_regularize=True               (:561-596)
+    Stored: the loss values and a strided sample + norm of every parameter gradient, fp32 and fp64."""
+    c = cases.TRAIN_STEP_CASE
+    hp = cases.TRAIN_HP
+    out = {}
+    size, b = c['size'], c['b']
+    n_latent = int(np.log2(size)) * 2 - 2
+    for dt, sfx in ((torch.float32, ''), (torch.float64, '64')):
+        e_tsr, e_w, e_wp = build_encoders(n_latent)
+        g = stylegan2.Generator(size, 512, 2)
+        g.load_state_dict(synth.state_dict('generator', g.state_dict(), seed=4))
+        d = stylegan2.Discriminator(size)
+        d.load_state_dict(synth.state_dict('discriminator', d.state_dict(), seed=8))
+        ge = dict(g=g, e_tsr=e_tsr, e_w=e_w, e_wp=e_wp)
+        for m in list(ge.values()) + [d]:
+            m.to(dt)
+        wrap = _GWrap(g)
+        photo = synth.tensor(c['name'] + '/photo', (b, 3, 256, 256), dist='uniform').to(dt)
+        render = synth.tensor(c['name'] + '/render', (b, 3, 256, 256), dist='uniform').to(dt)
+        ref = synth.tensor(c['name'] + '/ref', (b, 3, size, size), dist='uniform').to(dt)
+
+        def fwd(p_, r_, **kw):
+            return network_util.Forward_Inference_3_Encoder(p_, r_, e_tsr, e_w, e_wp, wrap, 'Photo Image', None, False, **kw)
+
+        def zero():
+            for m in list(ge.values()) + [d]:
+                m.zero_grad(set_to_none=True)
+
+        def req(ge_flag, d_flag):
+            for m in ge.values():
+                m.requires_grad_(ge_flag)
+            d.requires_grad_(d_flag)
+
+        # ---- d
+        req(False, True); zero()
+        fake = fwd(photo, render)
+        out_pred, ref_pred = d(fake), d(ref)
+        d_loss = ref_training_util.d_logistic_loss(ref_pred, out_pred)
+        d_loss.backward()
+        out['d/loss' + sfx] = np.float64(d_loss.item())
+        out['d/ref_score' + sfx] = np.float64(ref_pred.mean().item())
+        out['d/out_score' + sfx] = np.float64(out_pred.mean().item())
+        _sample_grads(out, 'd/d', d.named_parameters(), sfx)
+        # ---- r1
+        zero()
+        real = ref.clone().requires_grad_(True)
+        real_pred = d(real)
+        r1 = ref_training_util.d_r1_loss(real_pred, real)
+        (hp['r1'] / 2 * r1 * hp['d_reg_every'] + 0 * real_pred[0]).backward()
+        out['r1/loss' + sfx] = np.float64(r1.item())
+        _sample_grads(out, 'r1/d', d.named_parameters(), sfx)
+        # ---- g
+        req(True, False); zero()
+        fake = fwd(photo, render)
+        g_loss = ref_training_util.g_nonsaturating_loss(d(fake))
+        l1 = hp['l1_loss_lambda'] * ref_training_util.L1_Loss(fake, ref)
+        (g_loss + l1).backward()
+        out['g/loss' + sfx] = np.float64(g_loss.item())
+        out['g/l1' + sfx] = np.float64(l1.item())
+        for k, m in ge.items():
+            _sample_grads(out, 'g/' + k, m.named_parameters(), sfx)
+        # ---- ppl (batch / path_reg_batch_shrink; the reference picks the samples at random: fixed here)
+        zero()
+        idx = c['ppl_idx']
+        probe = synth.tensor(c['name'] + '/probe', (len(idx), 3, size, size)).to(dt)
+        with _FixedProbe(probe):
+            img, path_lengths = fwd(photo[idx], render[idx], PPL_regularize=True)
+        mean_path_length = 0
+        path_mean = mean_path_length + 0.01 * (path_lengths.mean() - mean_path_length)
+        path_loss = (path_lengths - path_mean).pow(2).mean()
+        weighted = hp['path_reg_weight'] * hp['g_reg_every'] * path_loss
+        weighted = weighted + 0 * img[0, 0, 0, 0]
+        weighted.backward()
+        out['ppl/loss' + sfx] = np.float64(path_loss.item())
+        out['ppl/lengths' + sfx] = npy(path_lengths)
+        for k, m in ge.items():
+            _sample_grads(out, 'ppl/' + k, m.named_parameters(), sfx)
+        print('  train_step', dt, d_loss.item(), r1.item(), g_loss.item(), l1.item(), path_loss.item())
+    np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **out)
+    print('train_step', len(out))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['upfirdn2d', 'fused_act', 'modules', 'generator', 'e2e', 'discriminator', 'image_io']
+    which = sys.argv[1:] or ['upfirdn2d', 'fused_act', 'modules', 'generator', 'e2e', 'discriminator', 'image_io',
+                             'e2e_grad', 'fp64', 'train_step']
     for w in which:
         {'upfirdn2d': gen_upfirdn2d, 'fused_act': gen_fused_act, 'modules': gen_modules,
          'generator': gen_generator, 'e2e': gen_encoders_e2e, 'discriminator': gen_discriminator,
-         'image_io': gen_image_io}[w]()
+         'image_io': gen_image_io, 'e2e_grad': gen_e2e_grad, 'fp64': gen_fp64, 'train_step': gen_train_step}[w]()
