@@ -7,7 +7,27 @@
 
 #define FMGAN_WAVE 64
 #define FMGAN_NUM_XCD 8
-#define FMGAN_NUM_CU 256
+
+// Compute units of the current device, asked once per device (MI355X: 256); feeds the grid caps and the split-K
+// model.  Without a device (host-logic calls in the CPU test-suite) the MI355X value is assumed, so host-only entry
+// points such as fmgan_modconv2d_workspace_bytes() answer the same on both boxes.
+static inline int fmgan_num_cu() {
+  static int cached[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  int v = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+    (void)hipGetLastError();
+    v = 256;
+  }
+  __atomic_store_n(&cached[dev], v, __ATOMIC_RELAXED);
+  return v;
+}
+#define FMGAN_NUM_CU fmgan_num_cu()
 
 static inline int fmgan_check_launch() {
   return hipGetLastError() == hipSuccess ? FMGAN_OK : FMGAN_ELAUNCH;

@@ -264,9 +264,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // (cin not a multiple of 8) takes the guarded path.
   // (An ablation showed the MFMA stages alone reach 140 TFLOP/s and the staging INSTRUCTIONS, not the bytes, are
   // what the co-resident block has to hide.)
-  const bool fastw = wvec && o0 + BM <= p.cout && (long long)p.cin * 9 * p.cout * 4 < (1LL << 32);
-  const bool fastx = (long long)seg_nb * p.cin * hw * 4 < (1LL << 32);
-  const unsigned w_bytes = (unsigned)((long long)p.cin * 9 * p.cout * 4);   // (the range check ignores soffset)
+  // The range check compares voffset (+4) with num_records and ignores soffset: a slot is "out of range" only through
+  // its parked voffset 0xFFFFFFF0, so the buffers must be SHORTER than that (with num_records >= 0xFFFFFFF4 a parked
+  // slot would pass the check and read base + 0xFFFFFFF0 + soffset).  Larger tensors take the guarded path.
+  constexpr long long PARK = 0xFFFFFFF0LL;
+  const bool fastw = wvec && o0 + BM <= p.cout && (long long)p.cin * 9 * p.cout * 4 < PARK;
+  const bool fastx = (long long)seg_nb * p.cin * hw * 4 < PARK;
+  const unsigned w_bytes = (unsigned)((long long)p.cin * 9 * p.cout * 4);
   const unsigned x_bytes = (unsigned)((long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4);
   const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, w_bytes, 0x00020000);
   const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b0), 0, x_bytes, 0x00020000);
@@ -1086,7 +1090,11 @@ int modconv2d_impl(const float* in, const float* wt, const float* style, const f
   p.out_plane_stride = out_plane_stride; p.out_row_stride = out_row_stride;
   p.noise = noise; p.noise_weight = noise_weight; p.bias = bias;
   p.noise_batch = noise_batch; p.fuse_act = fuse_act; p.alpha = alpha; p.act_scale = act_scale;
+  // index ranges the kernel relies on: pixel indices (y*ow + x, h*w) and per-chunk weight offsets are 32-bit ints,
+  // whole-tensor offsets are 64-bit; per-tile input offsets (nb*cin*h*w) are checked per segment in launch_cfg
   if ((long long)batch * cout * p.oh * p.ow > (1LL << 40)) return FMGAN_EOVERFLOW;
+  if ((long long)p.oh * p.ow >= (1LL << 31) || (long long)h * w >= (1LL << 31)) return FMGAN_EOVERFLOW;
+  if (cin > (1 << 20) || cout > (1 << 20)) return FMGAN_EOVERFLOW;
   hipStream_t s = (hipStream_t)stream;
   const int cfg = pick_cfg(mode, cout, (long long)batch * (mode == 2 ? p.oh * p.ow : h * w));
   // split-K only when the caller supplied the workspace fmgan_modconv2d_workspace_bytes() asks for
@@ -1175,6 +1183,7 @@ extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, cons
   if (w < 16) return FMGAN_EUNSUPPORTED;           // tiny layers: negligible FLOPs, the host keeps MIOpen's wgrad
   if (!go || !x || !style || !gw || !workspace) return FMGAN_EINVAL;
   if ((long long)batch * (cin > cout ? cin : cout) * h * w >= (1LL << 40)) return FMGAN_EOVERFLOW;
+  if ((long long)h * w >= (1LL << 31) || cin > (1 << 20) || cout > (1 << 20)) return FMGAN_EOVERFLOW;
   WGParams p{};
   p.go = go; p.d = demod; p.x = x; p.s = style; p.partial = (float*)workspace;
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;

@@ -40,6 +40,10 @@ WORKLOADS = {
     # eval-mode BatchNorm; with N > 1 the gradients are all-reduced by DDP over RCCL.
     'train256': dict(size=256, batch=16, desc='cfg3: full 3-encoder forward+backward @256^2, fp32, B=16/GPU, '
                      'grad all-reduce (DDP/RCCL) when N>1'),
+    # One iteration of train() (train_3_encoder.py:756-828) in fp32 with the losses available offline: D logistic loss,
+    # R1 every 16, G non-saturating + L1, path length every 4 on batch/2, EMA; Adam on G+encoders and on D.
+    'trainstep256': dict(size=256, batch=16, desc='train() iteration @256^2, fp32, B=16/GPU: D loss + R1/16 + G adv+L1 + '
+                         'path length/4 on B/2 + EMA, Adam; DDP/RCCL all-reduce of G/encoder and D gradients when N>1'),
 }
 
 
@@ -128,16 +132,38 @@ def make_train_step(nets, batch, device, rank, world):
     return step, (photo, render)
 
 
+def make_trainstep(nets, batch, device, rank, world, size):
+    """A full training iteration (3d-fm-gan_amd/train_3_encoder.py::Trainer.step) on synthetic pairs."""
+    import stylegan2
+    import train_3_encoder as T
+    torch.manual_seed(1)
+    d = stylegan2.Discriminator(size).to(device)
+    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+    render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
+    ref = (torch.rand(batch, 3, size, size, generator=gen) * 2 - 1).to(device)
+    tr = T.Trainer(dict(G=nets['g'], E_Tsr=nets['e_tsr'], E_W=nets['e_w'], E_W_Plus=nets['e_wp'], D=d),
+                   T.default_args(rec_batch=batch), device)
+
+    def step():
+        tr.step(photo, render, ref)
+
+    return step, tr
+
+
 def timed(step, steps, warmup, world):
     for _ in range(warmup):
         step()
+    gpu = torch.cuda.is_available()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if gpu:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    if gpu:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -147,6 +173,21 @@ def timed(step, steps, warmup, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     return dt
+
+
+def committed_traffic():
+    import glob
+    import hashlib
+    for tf in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_headline_traffic.json')), reverse=True):
+        rec = json.load(open(tf))
+        src = rec.get('kernel_source')
+        if not src or not os.path.exists(os.path.join(ROOT, src)):
+            continue
+        sha = hashlib.sha256(open(os.path.join(ROOT, src), 'rb').read()).hexdigest()
+        if sha != rec.get('kernel_source_sha256'):
+            return None, f'{os.path.relpath(tf, ROOT)} is stale: {src} changed since the counters were collected'
+        return rec['hbm_bytes_per_launch'], f"{os.path.relpath(tf, ROOT)} ({rec['source']}; kernel {rec.get('kernel')})"
+    return None, None
 
 
 def host_cores():
@@ -184,9 +225,108 @@ def cpu_baseline(nets, inputs, size, budget_s=20.0):
             if time.perf_counter() - t0 > budget_s or n >= 16:
                 break
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit='pairs/s', cores=cores, kind='port',
-                sample=f'{n} pairs at B=1 through oracle/torch_oracle.py (reference CPU path restated: F.conv2d '
-                       f'modconv + upfirdn2d_native + CPU fused_leaky_relu), Generator({size}), {dt:.1f} s')
+    out = dict(value=n / dt, unit='pairs/s', cores=cores, kind='port', cpu_model=cpu_model(),
+               sample=f'{n} pairs at B=1 through oracle/torch_oracle.py (reference CPU path restated: F.conv2d '
+                      f'modconv + upfirdn2d_native + CPU fused_leaky_relu), Generator({size}), {dt:.1f} s')
+    out['items'] = cpu_baseline_items(sds, photo, render, size)
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def _rate(fn, units, budget_s, max_n):
+    fn()                                   # first call pays allocator / thread-pool start-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= max_n:
+            break
+    return units * n / (time.perf_counter() - t0), n
+
+
+def cpu_baseline_items(sds, photo, render, size):
+    """The other CPU-fallback baselines BASELINE.md §3 lists, each on a bounded sample (same oracle, same cores):
+    cfg1 pair @256^2, synthesis-only @256^2 / @1024^2, and the two ops' algorithmic GB/s at the headline shapes
+    (upfirdn2d_native, op/upfirdn2d.py:168-209; CPU fused_leaky_relu, op/fused_act.py:114-125)."""
+    import math
+    from oracle import torch_oracle as T
+    items = {}
+    with torch.no_grad():
+        # ops at the headline shapes, B=1
+        x = torch.randn(1, 32, 1025, 1025)
+        k = T.make_kernel([1, 3, 3, 1]) * 4
+        r, n = _rate(lambda: T.upfirdn2d(x, k, pad=(1, 1)), 4.0 * 32 * (1025 * 1025 + 1024 * 1024) / 1e9, 4.0, 8)
+        items['upfirdn2d_native_blur_1x32x1025x1025'] = dict(value=r, unit='GB/s (algorithmic in+out)', calls=n)
+        x3 = torch.randn(1, 3, 512, 512)
+        r, n = _rate(lambda: T.upfirdn2d(x3, k, up=2, pad=(2, 1)), 4.0 * 3 * (512 * 512 + 1024 * 1024) / 1e9, 2.0, 16)
+        items['upfirdn2d_native_up2_1x3x512x512'] = dict(value=r, unit='GB/s (algorithmic in+out)', calls=n)
+        xa, ba = torch.randn(1, 32, 1024, 1024), torch.randn(32)
+        r, n = _rate(lambda: T.fused_leaky_relu(xa, ba), 8.0 * xa.numel() / 1e9, 3.0, 32)
+        items['fused_leaky_relu_1x32x1024x1024'] = dict(value=r, unit='GB/s (algorithmic read+write)', calls=n)
+        del x, xa
+        # synthesis only (cfg2's network at B=1) and the cfg1 pair
+        for sz in (256, 1024):
+            if sz == size:
+                sd_g = sds['g']
+            else:
+                import stylegan2
+                torch.manual_seed(0)
+                sd_g = {k_: v.detach() for k_, v in stylegan2.Generator(sz, 512, 8).state_dict().items()}
+            n_latent = int(round(math.log2(sz))) * 2 - 2
+            lat, tsr = torch.randn(1, n_latent, 512), torch.randn(1, 512, 4, 4)
+            r, n = _rate(lambda: T.generator_forward(sd_g, sz, lat, external_input_tensor=tsr), 1.0, 5.0, 8)
+            items[f'synthesis_only_{sz}_B1'] = dict(value=r, unit='images/s', calls=n)
+            if sz == 256:
+                sd_wp = sds['e_wp']
+                if size != 256:      # 14-style pSp encoder for the 256^2 generator
+                    from psp_encoder_model.encoders import psp_encoders
+                    torch.manual_seed(0)
+                    sd_wp = {k_: v.detach() for k_, v in psp_encoders.GradualStyleEncoder(
+                        18, 'ir_se', types.SimpleNamespace(input_nc=3, n_styles=14)).state_dict().items()}
+                r, n = _rate(lambda: T.forward_inference_3_encoder(photo, render, sds['e_tsr'], sds['e_w'], sd_wp, sd_g, 256),
+                             1.0, 6.0, 8)
+                items['cfg1_pair_256_B1'] = dict(value=r, unit='pairs/s', calls=n)
+    return items
+
+
+def plumbing(args):
+    """Everything of an N-rank bench run except the model: env rendezvous (gloo without GPUs), the shard of the global
+    batch this rank owns, warm-up, barrier-bracketed timing, MAX over ranks, one JSON line on rank 0."""
+    from Miscellaneous import distributed as D
+    rank, world, device = D.init_distributed()
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    wl = WORKLOADS[args.workload]
+    batch = args.batch or wl['batch']
+    lo, hi = D.shard_range(batch * world)
+    assert hi - lo == batch
+    x = torch.rand(batch, 64, 64)
+
+    def step():
+        time.sleep(0.002 * (rank + 1))          # ranks differ: the reported time must be the slowest rank's
+        return x @ x
+
+    dt = timed(step, args.steps, args.warmup, world)
+    counts = D.all_gather((rank, lo, hi))
+    if rank == 0:
+        assert sorted(counts) == [(r, r * batch, (r + 1) * batch) for r in range(world)], counts
+        print(json.dumps({'metric': '(photo,render) pairs/sec', 'value': world * batch * args.steps / dt, 'unit': 'pairs/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'plumbing test: no model, stand-in step',
+                          'config': {'workload': f'{args.workload} (plumbing only)', 'pairs_per_gpu': batch,
+                                     'global_pairs': batch * world, 'backend': dist.get_backend() if world > 1 else None}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -200,7 +340,12 @@ def main():
     ap.add_argument('--no-secondary', action='store_true')
     ap.add_argument('--graph', action='store_true', help='also time a HIP-graph replay of the forward and report it as '
                     'value (measured: no gain at these sizes, the step is GPU-bound)')
+    ap.add_argument('--no-train', action='store_true', help='skip the training legs (train256, trainstep256) of the default run')
+    ap.add_argument('--plumbing', action='store_true', help='no GPU work: a stand-in step through the same rendezvous, '
+                    'sharding, barrier + MAX-over-ranks timing and JSON contract (CPU/gloo test of the N>1 launch path)')
     args = ap.parse_args()
+    if args.plumbing:
+        return plumbing(args)
 
     import __graft_entry__
     # harness convenience on a fresh checkout (the product itself never builds): local rank 0 compiles, the others wait
@@ -210,7 +355,7 @@ def main():
     # let MIOpen pick each encoder convolution's kernel by measurement during warm-up (pSp encoder 10.7 -> 9.9 ms).
     # Forward workloads only: the exhaustive search over every backward-data / weight-gradient solver of the training
     # workload (it times MIOpen's naive reference kernels too) takes more than 7 minutes of warm-up.
-    torch.backends.cudnn.benchmark = args.workload != 'train256'
+    torch.backends.cudnn.benchmark = not args.workload.startswith('train')
     if torch.backends.cudnn.benchmark:
         # the search otherwise also times MIOpen's naive reference convolutions — 2.5 s of GPU time per process that can
         # never win; leaving them out shortens the warm-up (the same kernels get picked).  Set before the first conv.
@@ -223,16 +368,22 @@ def main():
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl['batch']
     nets = build_models(wl['size'], device)
-    if args.workload == 'train256':
-        step, inputs = make_train_step(nets, batch, device, rank, world)
+    if args.workload.startswith('train'):
+        if args.workload == 'train256':
+            step, inputs = make_train_step(nets, batch, device, rank, world)
+        else:
+            for m in nets.values():
+                m.requires_grad_(True)
+            step, _ = make_trainstep(nets, batch, device, rank, world, wl['size'])
         dt = timed(step, args.steps, args.warmup, world)
         if rank == 0:
             print(json.dumps({
-                'metric': '(photo,render) pairs/sec (forward+backward)', 'value': world * batch * args.steps / dt,
+                'metric': '(photo,render) pairs/sec (forward+backward)' if args.workload == 'train256' else
+                          '(photo,render) pairs/sec (training iteration)', 'value': world * batch * args.steps / dt,
                 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': f"train256: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
+                'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
                            'image_size': wl['size'], 'parallelism': f'dp{world} (DDP, 256 MiB buckets)' if world > 1 else 'single GPU'}}))
         if world > 1:
             dist.barrier()
@@ -274,11 +425,13 @@ def main():
         # algorithmic bytes of the blur: input + output (the fused noise row adds 1/C of the output and is not counted)
         bytes_alg = 4.0 * head[0] * (head[1] * head[2] + head[3] * head[4])
         ach = bytes_alg / (ms * 1e-3) / 1e9
+        # HBM traffic by PMC counters: the separate --pmc passes cannot run inside this process, so the committed
+        # rocprofv3 result is quoted — but only while it still describes the kernel that just ran: the record names the
+        # kernel source and its sha256 at measurement time (tools/headline_traffic.py writes it); after any edit of
+        # that source the number is stale and `traffic` is null until the counters are collected again.
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, 'profiles', 'r01_headline_traffic.json')
-        if batch == wl['batch'] and args.workload == 'pairs1024' and os.path.exists(tf):
-            rec = json.load(open(tf))       # PMC passes cannot run inside this process: committed rocprofv3 result
-            traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/r01_headline_traffic.json (' + rec['source'] + ')'
+        if batch == wl['batch'] and args.workload == 'pairs1024':
+            traffic, traffic_src = committed_traffic()
 
         out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_rowmarch_f32<4> (blur + fused noise/bias/lrelu store) [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
@@ -361,6 +514,26 @@ def main():
         out['config']['tertiary'] = 'cfg2: Generator(256) only, random W+ [32,14,512] and input tensor, fp32, B=32/GPU'
         del nets2, step2, g2net
         torch.cuda.empty_cache()
+        if not args.no_train:
+            # training legs (BASELINE config 3 and a full train() iteration at 256^2), fp32.  MIOpen in immediate mode:
+            # its exhaustive search over the backward solvers takes minutes.
+            torch.backends.cudnn.benchmark = False
+            t_steps, t_warm = max(3, args.steps // 4), 2
+            for name in ('train256', 'trainstep256'):
+                wt = WORKLOADS[name]
+                nets_t = build_models(wt['size'], device)
+                for m in nets_t.values():
+                    m.requires_grad_(True)
+                if name == 'train256':
+                    step_t, _ = make_train_step(nets_t, wt['batch'], device, rank, world)
+                else:
+                    step_t, _ = make_trainstep(nets_t, wt['batch'], device, rank, world, wt['size'])
+                dt_t = timed(step_t, t_steps, t_warm, world)
+                out[name + '_pairs_per_s'] = world * wt['batch'] * t_steps / dt_t
+                out[name + '_ms_per_step'] = 1e3 * dt_t / t_steps
+                out['config'][name] = f"{wt['desc']} ({t_steps} timed steps)"
+                del nets_t, step_t
+                torch.cuda.empty_cache()
         nets = build_models(wl['size'], device)
         _, inputs = make_step(nets, 1, device, rank)
 

@@ -201,3 +201,36 @@ def test_training_losses_on_cpu_tensors():
     assert torch.allclose(pl, torch.full((2,), math.sqrt(4 * 4))) and abs(mean.item() - 0.04) < 1e-6
     assert abs(pen.item() - (4 - 0.04) ** 2) < 1e-4
     assert abs(TU.L1_Loss(torch.zeros(2, 3), torch.full((2, 3), -2.0)).item() - 2.0) < 1e-7
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='passes fake pointers: host-side guard check for the CPU suite only')
+def test_modconv_index_range_guards_refuse_without_launching():
+    """Shapes just OUTSIDE each index-range guard of fmgan_modconv2d_f32 / fmgan_modconv_wgrad_f32 return
+    FMGAN_EOVERFLOW before anything is launched (the pointers here are fake).  The same guards from the inside —
+    shapes just below them must compute correctly — are GPU tests (tests/test_hip_modconv.py::test_guard_boundary_*)."""
+    L = _lib()
+    fake = ctypes.c_void_p(0x1000)
+    EOVER, EINVAL = -4, -1
+
+    def conv(batch, cin, cout, h, w, mode):
+        return L.fmgan_modconv2d_f32(fake, fake, fake, None, fake, batch, cin, cout, h, w, mode, None, None, None, 1, 0,
+                                     0.2, 1.4, 0, 0, None, 0, None)
+
+    # per-tile input offsets are 32-bit: (samples per tile) * cin * h * w must stay below 2^31 elements
+    assert conv(1, 8, 8, 16384, 16384, 0) == EOVER            # exactly 2^31
+    assert conv(1, 8, 8, 16384, 16384, 1) == EOVER
+    assert conv(1, 16, 8, 16384, 8192, 2) == EOVER
+    assert conv(1, 2049, 8, 1024, 1024, 0) == EOVER           # 2^31 + 2^20
+    # pixel indices y*ow + x are 32-bit
+    assert conv(1, 1, 1, 46341, 46341, 0) == EOVER
+    assert conv(1, 1, 1, 23171, 23171, 1) == EOVER            # output 46343^2
+    # channel counts beyond the 32-bit weight offsets
+    assert conv(1, (1 << 20) + 1, 8, 4, 4, 0) == EOVER
+    assert conv(1, 8, (1 << 20) + 1, 4, 4, 0) == EOVER
+    # whole-output element count
+    assert conv(70000, 512, 512, 256, 256, 0) == EOVER
+    # and the neighbouring failure classes stay distinct
+    assert conv(1, 8, 8, 0, 16, 0) == EINVAL
+    assert conv(1, 8, 8, 2, 2, 2) == EINVAL
+    assert L.fmgan_modconv_wgrad_f32(fake, None, fake, fake, fake, 1, 8, 8, 46341, 46341, 1.0, fake, 1 << 30, None) == EOVER
+    assert L.fmgan_modconv_wgrad_f32(fake, None, fake, fake, fake, 1, (1 << 20) + 1, 8, 32, 32, 1.0, fake, 1 << 30, None) == EOVER

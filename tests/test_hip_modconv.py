@@ -342,3 +342,67 @@ def test_modconv_random_shapes_vs_c_oracle():
         dm = _native.modconv_demod(wd, sd, scale) if demod else None
         y = _native.modconv2d(xd, wt, sd, dm, mode)
         np.testing.assert_allclose(y.cpu().numpy(), ref, err_msg=f'mode {mode} b{b} {cin}->{cout} {h}x{w}', **_tol(ref))
+
+
+# ---------------------------------------------------------------------------------------- index-range guard boundary
+# Shapes just INSIDE the guards of fmgan_modconv2d_f32 (csrc/modconv.hip: 32-bit per-tile input offsets
+# nb*cin*h*w < 2^31 elements; buffer-load staging only for tensors shorter than the parked voffset 0xFFFFFFF0 bytes)
+# must compute correctly; shapes just outside return FMGAN_EOVERFLOW without launching (tests/test_abi_host.py).
+# The tensors are 4-9 GB, so the check is the convolution's locality: output windows (all four corners, the last
+# rows/columns, the middle) against the C oracle run on the matching input crop.
+def _window_check(xd, wgt, s, y, mode, y0, x0, wh, ww):
+    from oracle import c_oracle
+    b, cin, h, w = xd.shape
+    if mode == 0:          # out[y,x] <- in[y-1..y+1, x-1..x+1]
+        iy0, ix0 = y0 - 1, x0 - 1
+        ih, iw = wh + 2, ww + 2
+    else:                  # mode 1: out[Y,X] <- in[(Y-2)/2 .. Y/2]; window start even
+        assert y0 % 2 == 0 and x0 % 2 == 0
+        iy0, ix0 = y0 // 2 - 1, x0 // 2 - 1
+        ih, iw = wh // 2 + 2, ww // 2 + 2
+    crop = torch.zeros(b, cin, ih, iw)
+    sy0, sx0 = max(iy0, 0), max(ix0, 0)
+    sy1, sx1 = min(iy0 + ih, h), min(ix0 + iw, w)
+    crop[:, :, sy0 - iy0:sy1 - iy0, sx0 - ix0:sx1 - ix0] = xd[:, :, sy0:sy1, sx0:sx1].cpu()
+    ref = c_oracle.modulated_conv2d(crop.numpy(), wgt.numpy(), s.numpy(), mode=mode, demodulate=True)
+    if mode == 0:
+        ref = ref[:, :, 1:1 + wh, 1:1 + ww]
+    else:                  # crop row r holds input row iy0 + r: output row Y = 2*(iy0 + r) + ky
+        oy, ox = y0 - 2 * iy0, x0 - 2 * ix0
+        ref = ref[:, :, oy:oy + wh, ox:ox + ww]
+    got = y[:, :, y0:y0 + wh, x0:x0 + ww].cpu().numpy()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    np.testing.assert_allclose(got, ref, **_tol(ref))
+
+
+@pytest.mark.parametrize('cfg', [
+    # (cin, cout, h, w, mode, what)
+    (8, 8, 8192, 16383, 0, 'buffer-load staging, 0xFFF0_0000 bytes of input: just below the parked-voffset limit'),
+    (8, 8, 8192, 16384, 0, 'exactly 2^32 bytes of input: guarded staging path'),
+    (8, 8, 16384, 16383, 0, '2^31 - 2^17 input elements: just inside the 32-bit offset guard'),
+    (8, 4, 8192, 16383, 1, 'transposed conv, input just below the parked-voffset limit, 8.6 GB output'),
+], ids=['fastx_max', 'fastx_off', 'offset_guard_max', 'fastx_max_transposed'])
+def test_guard_boundary_shapes_compute_correctly(cfg):
+    from op import _native
+    cin, cout, h, w, mode, _ = cfg
+    gen = torch.Generator(device=dev()).manual_seed(1234)
+    xd = torch.randn(1, cin, h, w, device=dev(), generator=gen)
+    wgt = synth.tensor(f'guard/{cfg[:5]}/w', (cout, cin, 3, 3))
+    s = synth.tensor(f'guard/{cfg[:5]}/s', (1, cin), shift=1.0, scale=0.5)
+    scale = 1.0 / np.sqrt(cin * 9)
+    wd, sd = wgt.to(dev()), s.to(dev())
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale)
+    y = _native.modconv2d(xd, wt, sd, dm, mode)
+    oh, ow = y.shape[2:]
+    assert (oh, ow) == ((2 * h + 1, 2 * w + 1) if mode == 1 else (h, w))
+    # windows reach the last output row and column; for the transposed conv (odd output sizes) origins are even
+    wsz = 25 if mode == 1 else 24
+    ey, ex = oh - wsz, ow - wsz
+    mid_y, mid_x = (oh // 2) & ~1, (ow // 3) & ~1
+    wins = [(0, 0), (0, ex), (ey, 0), (ey, ex), (mid_y, mid_x), (ey, mid_x), (mid_y, ex)]
+    for (y0, x0) in wins:
+        _window_check(xd, wgt, s, y, mode, y0, x0, wsz, wsz)
+    assert torch.isfinite(y[:, :, ::997, ::991]).all()
+    del y, xd
+    torch.cuda.empty_cache()

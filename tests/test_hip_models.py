@@ -22,11 +22,28 @@ def _load(module, kind, seed):
     return module.to(dev()).eval()
 
 
+def _fp64():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fp64.npz'))
+
+
+def _no_farther_than_reference(a, ref32, ref64, floor=2e-6, margin=4.0):
+    """|HIP - fp64| <= margin * |reference fp32 - fp64| + floor * max|fp64|: the HIP(+MIOpen) result is as close to the
+    exact value as the reference's own fp32 result (fixtures: tools/make_golden.py gen_fp64)."""
+    scale = float(np.abs(ref64).max())
+    e_hip = float(np.abs(a.astype(np.float64) - ref64).max()) / scale
+    e_ref = float(np.abs(ref32.astype(np.float64) - ref64).max()) / scale
+    assert e_hip <= margin * e_ref + floor, (e_hip, e_ref)
+
+
 def _img_close(img, g, name, stride, rel=1e-4):
     a = img.detach().float().cpu().numpy()
     ref = g[name + '/sub']
     scale = float(np.abs(ref).max())
     np.testing.assert_allclose(a[..., ::stride, ::stride], ref, atol=rel * scale, rtol=rel)
+    f64 = _fp64()
+    if name + '/sub' in f64.files:
+        _no_farther_than_reference(a[..., ::stride, ::stride], ref, f64[name + '/sub'])
     st = g[name + '/stats']
     a64 = a.astype(np.float64)
     np.testing.assert_allclose([a64.mean(), np.abs(a64).mean()], st[:2], atol=rel * scale, rtol=rel)
@@ -35,7 +52,9 @@ def _img_close(img, g, name, stride, rel=1e-4):
 
 @pytest.mark.parametrize('c', cases.GENERATOR_CASES, ids=lambda c: c['name'])
 def test_generator_golden(c, golden):
-    """End-to-end image tolerance 1e-4 of the image's max-abs."""
+    """End-to-end image tolerance 1e-4 of the image's max-abs; measured on MI355X
+    (profiles/r02_parity_errors.md): 1.1e-6 .. 2.6e-6 vs the reference's fp32 output, 0.9e-6 .. 2.1e-6 vs its fp64
+    output (the reference's own fp32-vs-fp64 distance: 0.8e-6 .. 1.9e-6)."""
     import stylegan2
     g = golden('generator')
     G = _load(stylegan2.Generator(c['size'], 512, c['n_mlp'], generator_net_shape=c['shape']), 'generator', 4)
@@ -103,15 +122,18 @@ def test_forward_inference_3_encoder_golden(c, golden):
     G = _load(stylegan2.Generator(c['size'], 512, 8), 'generator', 4)
     p = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform').to(dev())
     r = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform').to(dev())
+    # Tolerances = measured error x ~5 (profiles/r02_parity_errors.md).  Encoders (MIOpen convolutions, summation order
+    # differs from the CPU reference): measured 1.5e-7 .. 7.1e-7 of max|out| -> 5e-6.  End-to-end image: BASELINE.md §4
+    # asks atol = rtol = 1e-4; measured 1.2e-6 .. 1.8e-6, and 1.1e-5 for the tanh case whose max is 1 -> 5e-5.
+    f64 = _fp64()
     with torch.no_grad():
-        np.testing.assert_allclose(e_tsr(p).cpu().numpy(), g[c['name'] + '/e_tsr'], atol=5e-4, rtol=5e-4)
-        np.testing.assert_allclose(e_w(r).cpu().numpy(), g[c['name'] + '/e_w'], atol=5e-4, rtol=5e-4)
-        ref_wp = g[c['name'] + '/e_wplus']
-        np.testing.assert_allclose(e_wp(p).cpu().numpy(), ref_wp, atol=5e-4 * np.abs(ref_wp).max(), rtol=5e-4)
+        for net, x, key in ((e_tsr, p, 'e_tsr'), (e_w, r, 'e_w'), (e_wp, p, 'e_wplus')):
+            out, ref = net(x).cpu().numpy(), g[f"{c['name']}/{key}"]
+            np.testing.assert_allclose(out, ref, atol=5e-6 * np.abs(ref).max(), rtol=1e-4)
+            _no_farther_than_reference(out, ref, f64[f"{c['name']}/{key}"])
         img = Forward_Inference_3_Encoder(p, r, e_tsr, e_w, e_wp, _PinNoise(G), tsr_encode=c['tsr_encode'],
                                           sliced_layer=c['sliced_layer'], use_tanh=c['use_tanh'])
-    # encoders run on MIOpen (different summation order than the CPU reference): 1e-3 of max-abs end to end
-    _img_close(img, g, c['name'], c['stride'], rel=1e-3)
+    _img_close(img, g, c['name'], c['stride'], rel=5e-5)
 
 
 @pytest.mark.parametrize('c', cases.DISCRIMINATOR_CASES, ids=lambda c: c['name'])
@@ -123,7 +145,9 @@ def test_discriminator_golden(c, golden):
     with torch.no_grad():
         y = D(x)
     ref = g[c['name'] + '/out']
-    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=1e-3 * max(1.0, np.abs(ref).max()), rtol=1e-3)
+    # measured 2.0e-7 .. 5.4e-7 of max|out| (profiles/r02_parity_errors.md) -> 5e-6
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=5e-6 * np.abs(ref).max(), rtol=1e-4)
+    _no_farther_than_reference(y.cpu().numpy(), ref, _fp64()[c['name'] + '/out'])
 
 
 def test_generator_gradients_and_path_length_vs_oracle():

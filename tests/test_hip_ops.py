@@ -33,7 +33,7 @@ def test_upfirdn2d_golden(c, golden):
     y = upfirdn2d(x, k, up=c['up'], down=c['down'], pad=tuple(c['pad']))
     np.testing.assert_allclose(y.cpu().numpy(), ref, **OP_TOL)
     # every kernel path that accepts these arguments gives the same answer
-    for path in (0, 1, 2, 3, 5):
+    for path in (0, 1, 2, 3):
         try:
             yp = _run_ufd(x, k, c, path)
         except RuntimeError as e:

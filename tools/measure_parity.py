@@ -93,7 +93,7 @@ def main():
     reports = []
     for k, m in nets.items():
         rep = []
-        H.check_grads(g, k, m.named_parameters(), report=rep, margin=1e9)
+        H.check_grads(g, k, m.named_parameters(), report=rep, margin=1e9, floor=1e9)
         reports.append((k, rep))
     grad_table('cfg3: gradients of the L1 loss through G and the three encoders (e2e_256_grad, B=2)', reports)
     del nets
@@ -110,7 +110,7 @@ def main():
         ks = ('d',) if phase in ('d', 'r1') else ('g', 'e_tsr', 'e_w', 'e_wp')
         for k in ks:
             rep = []
-            H.check_grads(g, f'{phase}/{k}', nets[k].named_parameters(), report=rep, margin=1e9)
+            H.check_grads(g, f'{phase}/{k}', nets[k].named_parameters(), report=rep, margin=1e9, floor=1e9)
             reports.append((f'{phase}: {k}', rep))
         vals = {k: (v.item() if v.numel() == 1 else v.detach().cpu().numpy().tolist()) for k, v in ld.items()}
         print(f'\nphase {phase}: HIP {vals}; fixture fp64 ' +

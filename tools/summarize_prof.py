@@ -136,6 +136,12 @@ def headline_traffic(out, tag):
                                 'FETCH_SIZE_KiB_per_launch': sum(fa) / len(fa), 'WRITE_SIZE_KiB_per_launch': sum(wa) / len(wa),
                                 'launches_sampled': [len(fa), len(wa)], 'hbm_bytes_per_launch': mb(fa, wa)}
     doc['hbm_bytes_per_launch'] = doc['in_step']['hbm_bytes_per_launch']
+    # staleness guard read by bench.py::committed_traffic: the number describes THIS version of the kernel source
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = '3d-fm-gan_amd/csrc/upfirdn2d.hip'
+    doc['kernel_source'] = src
+    doc['kernel_source_sha256'] = hashlib.sha256(open(os.path.join(root, src), 'rb').read()).hexdigest()
     with open(os.path.join(out, 'headline_traffic.json'), 'w') as fh:
         json.dump(doc, fh, indent=1)
 
