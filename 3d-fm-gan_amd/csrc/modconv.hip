@@ -20,6 +20,8 @@
 //   * Tiny layers (4x4 .. 8x8) pack several samples into one pixel tile.
 // Demodulation: one wave per output channel, sum over Cin by wave-shuffle butterfly.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -129,6 +131,9 @@ struct MCParams {
   const float* rgb_wmod;   // [batch][3][cout] = rgb_scale * W[c,o] * rgb_style[b,o], rows >= rgb_c zero
   const float* rgb_bias; const float* rgb_skip; float* rgb_out;
   int rgb_c;
+  // PIPE 1 (all staging by LDS-DMA): floats per LDS buffer = weights + patch region + style region, and the patch
+  // region's size (both rounded to 64 floats so every DMA piece of 64 lanes x 4 B stays inside its region)
+  int lds_buf_floats, lds_patch_floats;
 };
 
 constexpr int MC_KC = 8;  // input channels per LDS chunk
@@ -170,10 +175,19 @@ __device__ __forceinline__ float mc_epilogue(float v, const MCParams& p, float n
 // 1820 vs 1603 us, 1550 vs 1400 us (512^2), transposed 1033 vs 890 us: co-resident blocks beat longer chunks.  Not kept.
 // The 128 x 128 tile on 8 waves (512 threads, each wave 64 x 32, 4 waves per SIMD in a 128-register budget): 24 VGPRs
 // spill and it ties with the 4-wave tile (123.6 vs 125.0 TFLOP/s at 64^2).  Not kept.)
-template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false, int MINB = 2>
+// PIPE 0: register-prefetch staging (global -> VGPR one chunk ahead -> ds_write after a barrier; two barriers per chunk).
+// PIPE 1: everything a chunk needs — weights (16-byte pieces), the halo patch and the style slice (4-byte pieces) — is
+//         written into LDS by `buffer_load ... lds` (LDS-DMA: no VGPR destination, no ds_write, no commit phase), into
+//         the buffer the PREVIOUS chunk is not reading; one barrier per chunk.  The style modulation moves from the
+//         staging write to the operand fetch (x * s in a VALU op right before the MFMA: the same fp32 product, so both
+//         pipelines give identical bits).  Patch slots outside the image rely on the buffer range check: their
+//         voffset is parked out of range and the DMA writes zeros (tools/exp/dma_probe.hip).  Chunks that the range check
+//         cannot serve (a partial last chunk, tensors of 4 GB and more, ragged Cout) are filled synchronously instead.
+template <int MODE, int RM, int RNP, int WM, int WN, bool RGB = false, int MINB = 2, int KC_ = MC_KC, int PIPE = 0>
 __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) {
   static_assert(!RGB || MODE == 0, "the RGB epilogue belongs to the plain conv");
-  constexpr int KC = MC_KC;
+  constexpr int KC = KC_;
+  static_assert(PIPE == 1 || KC == MC_KC, "the register pipeline is built for 8-channel chunks");
   constexpr int BM = 32 * RM * WM;
   constexpr int NPH = MODE == 1 ? 4 : 1;   // output phases per position
   static_assert(WM * WN == 4, "4 waves per block");
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     const int r = t % PH, nbi = t / PH;
     const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG;
     inb[u] = q < spatial && b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
-    gofs[u] = (nbi * p.cin * p.h + y) * p.w + x;
+    gofs[u] = inb[u] ? (nbi * p.cin * p.h + y) * p.w + x : 0;
     sofs[u] = nbi * p.cin;
     lofs[u] = q < spatial ? nbi * samp + r * PWP + c : -1;
   }
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // slot would pass the check and read base + 0xFFFFFFF0 + soffset).  Larger tensors take the guarded path.
   constexpr long long PARK = 0xFFFFFFF0LL;
   const bool fastw = wvec && o0 + BM <= p.cout && (long long)p.cin * 9 * p.cout * 4 < PARK;
-  const bool fastx = (long long)seg_nb * p.cin * hw * 4 < PARK;
+  const bool fastx = (long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4 < PARK;
   const unsigned w_bytes = (unsigned)((long long)p.cin * 9 * p.cout * 4);
   const unsigned x_bytes = (unsigned)((long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4);
   const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, w_bytes, 0x00020000);
@@ -370,16 +384,28 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   constexpr int NTA = MODE == 1 ? 9 : 3;     // A (weight) values per stage per 32-row tile
   constexpr int NTB = MODE == 1 ? 4 : 3;     // B (input) values per stage per position group
   constexpr int NSTAGE = (KC / 2) * (MODE == 1 ? 1 : 3);
-  struct Ops { float a[NTA][RM]; float b[NTB][RNP]; };
+  struct Ops { float a[NTA][RM]; float b[NTB][RNP]; float s[RNP]; };
+  const float* Wc = Ws;            // LDS image the current chunk is read from (PIPE 1: toggles between two buffers)
+  const float* Xc = Xs;
+  const float* Sc = nullptr;       // PIPE 1: style slice [nb][KC] of the chunk
+  int sbase[RNP];                  // PIPE 1: this lane's sample row in the style slice
+#pragma unroll
+  for (int g = 0; g < RNP; ++g) sbase[g] = (pbase[g] / samp) * KC;
   auto fetch = [&](Ops& o, int st) {
     const int kk = MODE == 1 ? st : st / 3, ky = MODE == 1 ? 0 : st % 3;
     const int kc = 2 * kk + khalf;
-    const float* wrow = Ws + (kc * 9 + ky * 3) * BM + wm * 32 * RM + l31;
-    const float* xrow = Xs + kc * plane;
+    const float* wrow = Wc + (kc * 9 + ky * 3) * BM + wm * 32 * RM + l31;
+    const float* xrow = Xc + kc * plane;
 #pragma unroll
     for (int t = 0; t < NTA; ++t)
 #pragma unroll
       for (int m = 0; m < RM; ++m) o.a[t][m] = wrow[t * BM + m * 32];
+    if constexpr (PIPE == 1) {
+      if (MODE == 1 || ky == 0) {
+#pragma unroll
+        for (int g = 0; g < RNP; ++g) o.s[g] = Sc[sbase[g] + kc];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NTB; ++j) {
       // MODE 0: offset (ky, kx = j); MODE 1: j -> (ro, co) = (1,1) (1,0) (0,1) (0,0)
@@ -387,6 +413,15 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       const int co = MODE == 1 ? 1 - (j & 1) : j;
 #pragma unroll
       for (int g = 0; g < RNP; ++g) o.b[j][g] = xrow[pbase[g] + ro * PWP + co];
+    }
+  };
+  // PIPE 1: x * style[b, i] on the way to the matrix pipe (PIPE 0 did it on the way into LDS)
+  auto modulate = [&](Ops& o) {
+    if constexpr (PIPE == 1) {
+#pragma unroll
+      for (int j = 0; j < NTB; ++j)
+#pragma unroll
+        for (int g = 0; g < RNP; ++g) o.b[j][g] *= o.s[g];
     }
   };
   auto mma = [&](const Ops& o) {
@@ -412,26 +447,152 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     }
   };
 
-  if (i_begin < i_end) issue(i_begin);
-  for (int i0 = i_begin; i0 < i_end; i0 += KC) {
-    __syncthreads();            // every wave is done reading the previous chunk
-    commit(i0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    if (i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
-    // ---- contract: operands of channel pair kk+1 are fetched while pair kk is on the matrix pipe.
-    // (hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) in front of each group of four:
-    // the sched_barriers keep "issue all reads of pair kk+1, then run pair kk's MFMAs" as written.)
+  // ---- contract: operands of stage st+1 are fetched while stage st is on the matrix pipe.
+  // (hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) in front of each group of four:
+  // the sched_barriers keep "issue all reads of stage st+1, then run stage st's MFMAs" as written.)
+  auto contract = [&]() {
     Ops cur, nxt;
     fetch(cur, 0);
 #pragma unroll
     for (int st = 0; st < NSTAGE; ++st) {
       __builtin_amdgcn_sched_barrier(0);
-      if (st + 1 < NSTAGE) fetch(nxt, st + 1);
+      if (st + 1 < NSTAGE) {
+        fetch(nxt, st + 1);
+        if constexpr (PIPE == 1 && MODE != 1) {
+          // the style value of a channel pair is read with its first tap row and reused for the other two
+          if ((st + 1) % 3 != 0) {
+#pragma unroll
+            for (int g = 0; g < RNP; ++g) nxt.s[g] = cur.s[g];
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      modulate(cur);
       mma(cur);
       __builtin_amdgcn_sched_barrier(0);
       if (st + 1 < NSTAGE) cur = nxt;
+    }
+  };
+
+  if constexpr (PIPE == 0) {
+    if (i_begin < i_end) issue(i_begin);
+    for (int i0 = i_begin; i0 < i_end; i0 += KC) {
+      __syncthreads();            // every wave is done reading the previous chunk
+      commit(i0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
+      contract();
+    }
+  } else {
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    constexpr unsigned PARKED = 0xFFFFFFF0u;
+    constexpr int WSZ = KC * 9 * BM;                        // floats of one weight image
+    constexpr int WPIECES = WSZ / 256;                      // 16-byte pieces (64 lanes x 16 B = 256 floats)
+    static_assert(WSZ % 256 == 0, "weight image = whole DMA pieces");
+    constexpr int NWP = (WPIECES + 3) / 4;                  // per wave
+    constexpr int NUP = ((KC * (SP * (BNP / 32 - 1) + 3) * (SP * 31 + 3) + 63) / 64 + 3) / 4;   // patch pieces per wave, main tile
+    const int xs_total = seg_nb * samp;                     // patch floats
+    const int x_pieces = (xs_total + 63) >> 6;
+    const int s_pieces = (seg_nb * KC + 63) >> 6;
+    const int bstride = p.lds_buf_floats;
+    const bool fastc = fastw && fastx;                      // DMA-servable tensors (chunk completeness checked per chunk)
+    const unsigned s_bytes = (unsigned)(min(seg_nb, p.batch - b0) * p.cin * 4);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(style_b0), 0, s_bytes, 0x00020000);
+    // patch element (linear LDS index) -> byte offset from in_b0 of channel i0, or PARKED
+    auto x_voff = [&](int e) -> unsigned {
+      if (e >= xs_total) return PARKED;
+      const int nbi = e / samp, rem = e - nbi * samp;
+      const int kc = rem / plane, q = rem - kc * plane;
+      const int r = q / PWP, c = q - r * PWP;
+      const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG;
+      const bool ok = b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
+      return ok ? (unsigned)(((nbi * p.cin + kc) * p.h + y) * p.w + x) * 4u : PARKED;
+    };
+    auto s_voff = [&](int e) -> unsigned {
+      const int nbi = e / KC, kc = e - nbi * KC;
+      return (nbi < seg_nb && b0 + nbi < p.batch) ? (unsigned)(nbi * p.cin + kc) * 4u : PARKED;
+    };
+    unsigned wvo[NWP], xvo[NUP];
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) {
+      const int idx = (4 * j + wave) * 64 + lane;           // float4 index in the image [KC*9][BM/4]
+      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+      wvo[j] = (unsigned)((row * p.cout + o0 + c4 * 4) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NUP; ++u) xvo[u] = x_voff((4 * u + wave) * 64 + lane);
+    const unsigned svo = s_voff(wave * 64 + lane);          // first style piece of this wave (all of them when nb*KC <= 256)
+
+    auto stage = [&](int i0, int buf) {
+      float* Wb = smem + buf * bstride;
+      float* Xb = Wb + WSZ;
+      float* Sb = Xb + p.lds_patch_floats;
+      if (fastc && i0 + KC <= i_end) {
+        const unsigned soff_w = (unsigned)(i0 * 9 * p.cout * 4);
+        const unsigned soff_x = (unsigned)(i0 * hw * 4);
+#pragma unroll
+        for (int j = 0; j < NWP; ++j)
+          if (4 * j + wave < WPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_ptr)(Wb + (4 * j + wave) * 256), 16, wvo[j], soff_w, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NUP; ++u)
+          if (4 * u + wave < x_pieces)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_void_ptr)(Xb + (4 * u + wave) * 64), 4, xvo[u], soff_x, 0, 0);
+        for (int pc = 4 * NUP + wave; pc < x_pieces; pc += 4)       // patches larger than a main tile's
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_void_ptr)(Xb + pc * 64), 4, x_voff(pc * 64 + lane), soff_x, 0, 0);
+        if (wave < s_pieces)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_void_ptr)(Sb + wave * 64), 4, svo, (unsigned)(i0 * 4), 0, 0);
+        for (int pc = 4 + wave; pc < s_pieces; pc += 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_void_ptr)(Sb + pc * 64), 4, s_voff(pc * 64 + lane), (unsigned)(i0 * 4), 0, 0);
+      } else {
+        // guarded synchronous fill (same images, zeros where the DMA's range check would have produced them)
+        for (int idx = tid; idx < KC * 9 * (BM / 4); idx += 256) {
+          const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+          const int i = i0 + row / 9, o = o0 + c4 * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (i < i_end) {
+            const float* src = p.wt + ((long long)i * 9 + row % 9) * p.cout + o;
+            if (o + 0 < p.cout) v.x = src[0];
+            if (o + 1 < p.cout) v.y = src[1];
+            if (o + 2 < p.cout) v.z = src[2];
+            if (o + 3 < p.cout) v.w = src[3];
+          }
+          *reinterpret_cast<f32x4*>(Wb + idx * 4) = v;
+        }
+        for (int e = tid; e < (x_pieces << 6); e += 256) {
+          float v = 0.f;
+          if (e < xs_total) {
+            const int nbi = e / samp, rem = e - nbi * samp;
+            const int kc = rem / plane, q = rem - kc * plane;
+            const int r = q / PWP, c = q - r * PWP;
+            const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG, i = i0 + kc;
+            if (b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w && i < i_end)
+              v = p.in[(((long long)b * p.cin + i) * p.h + y) * p.w + x];
+          }
+          Xb[e] = v;
+        }
+        for (int e = tid; e < seg_nb * KC; e += 256) {
+          const int nbi = e / KC, kc = e - nbi * KC;
+          Sb[e] = (b0 + nbi < p.batch && i0 + kc < i_end) ? p.style[(long long)(b0 + nbi) * p.cin + i0 + kc] : 0.f;
+        }
+      }
+    };
+
+    if (i_begin < i_end) stage(i_begin, 0);
+    int buf = 0;
+    for (int i0 = i_begin; i0 < i_end; i0 += KC, buf ^= 1) {
+      // this wave's DMA pieces / LDS stores of chunk i0 have landed; after the barrier everyone's have, and every wave
+      // has finished reading the other buffer (its ds_reads were retired before the MFMAs that consumed them)
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (i0 + KC < i_end) stage(i0 + KC, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      Wc = smem + buf * bstride;
+      Xc = Wc + WSZ;
+      Sc = Xc + p.lds_patch_floats;
+      contract();
     }
   }
 
@@ -439,58 +600,67 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // `if` costs one full memory round trip per element, 64 of them in a row per thread), then arithmetic on the
   // accumulators in place, then predicated stores.
   const bool partial = p.ksplit > 1;
-  const bool actf = p.fuse_act && !partial;
+  const bool actf = MODE == 0 && p.fuse_act && !partial;
   const bool use_demod = p.demod != nullptr && !partial;
   const float nw = (actf && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
   float* dstbase = partial ? p.ws + (long long)ks * p.batch * p.cout * p.oh * p.ow : p.out;
   const long long dps = partial ? (long long)p.oh * p.ow : p.out_plane_stride;
   const int drs = partial ? p.ow : p.out_row_stride;
   const int orow = o0 + wm * 32 * RM + 4 * khalf;     // this lane's first output channel; row r adds (r&3) + 8*(r>>2)
-  float bias_v[RM][16], dm[RM][16];
-#pragma unroll
-  for (int m = 0; m < RM; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
-      bias_v[m][r] = (actf && p.bias) ? p.bias[oc] : 0.f;
-      dm[m][r] = 1.f;
-    }
+  // per position group: validity, destination, noise term (loaded up front, clamped indices)
+  bool vgs[RNP]; float* dposs[RNP]; float nzs[RNP];
 #pragma unroll
   for (int g = 0; g < RNP; ++g) {
     const int b = pos_b[g], bc = min(b, p.batch - 1);
-    if (use_demod && (g == 0 || seg_nb > 1)) {        // tiles of one sample (every large layer) load demod once
-#pragma unroll
-      for (int m = 0; m < RM; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          dm[m][r] = p.demod[(long long)bc * p.cout + min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1)];
-    }
     if constexpr (MODE != 1) {
       const int y = pos_y[g], x = pos_x[g];
-      const bool vg = b < p.batch && y < p.oh && x < p.ow;
-      const int pix = vg ? y * p.ow + x : 0;
-      const float nz = (actf && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : bc) * p.oh * p.ow + pix]) : 0.f;
-      float* dpos = dstbase + (long long)bc * p.cout * dps + (long long)(vg ? y : 0) * drs + (vg ? x : 0);
+      vgs[g] = b < p.batch && y < p.oh && x < p.ow;
+      const int pix = vgs[g] ? y * p.ow + x : 0;
+      nzs[g] = (actf && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : bc) * p.oh * p.ow + pix]) : 0.f;
+      dposs[g] = dstbase + (long long)bc * p.cout * dps + (long long)(vgs[g] ? y : 0) * drs + (vgs[g] ? x : 0);
+    } else {
+      vgs[g] = b < p.batch && pos_y[g] < seg_m_end && pos_x[g] < seg_n_end;
+      nzs[g] = 0.f;
+      dposs[g] = dstbase + (long long)bc * p.cout * dps + (long long)(vgs[g] ? 2 * pos_y[g] : 0) * drs + (vgs[g] ? 2 * pos_x[g] : 0);
+    }
+  }
+  // One 32-channel row group at a time: its bias / demodulation values are loaded together (16 + 16 registers live
+  // beside the accumulators instead of 32 * RM + 32 * RM: what lets the 128 x 128 tile fit three blocks per CU).
 #pragma unroll
-      for (int m = 0; m < RM; ++m)
+  for (int m = 0; m < RM; ++m) {
+    float bias_m[16], dm_m[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
+      bias_m[r] = (actf && p.bias) ? p.bias[oc] : 0.f;
+      dm_m[r] = 1.f;
+    }
+#pragma unroll
+    for (int g = 0; g < RNP; ++g) {
+      const int bc = min(pos_b[g], p.batch - 1);
+      if (use_demod && (g == 0 || seg_nb > 1)) {        // tiles of one sample (every large layer) load demod once
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dm_m[r] = p.demod[(long long)bc * p.cout + min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1)];
+      }
+      const bool vg = vgs[g];
+      float* dpos = dposs[g];
+      if constexpr (MODE != 1) {
+        const float nz = nzs[g];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc[m][g][0][r] * dm[m][r];
+          float v = acc[m][g][0][r] * dm_m[r];
           if (actf) {
-            v = __fadd_rn(__fadd_rn(v, nz), bias_v[m][r]);
+            v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
             v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
           }
           if constexpr (RGB) acc[m][g][0][r] = (vg && o < p.cout) ? v : 0.f;
           if ((!RGB || dstbase) && vg && o < p.cout) dpos[(long long)o * dps] = v;
         }
-    } else {
-      const bool vg = b < p.batch && pos_y[g] < seg_m_end && pos_x[g] < seg_n_end;
-      const int X = 2 * pos_x[g], Y0 = 2 * pos_y[g];
-      const bool pair = X + 1 < p.ow;
-      float* dpos = dstbase + (long long)bc * p.cout * dps + (long long)(vg ? Y0 : 0) * drs + (vg ? X : 0);
-#pragma unroll
-      for (int m = 0; m < RM; ++m)
+      } else {
+        const int X = 2 * pos_x[g], Y0 = 2 * pos_y[g];
+        const bool pair = X + 1 < p.ow;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
@@ -499,7 +669,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
 #pragma unroll
           for (int py = 0; py < 2; ++py) {
             if (Y0 + py >= p.oh) continue;
-            const float v0 = acc[m][g][py * 2][r] * dm[m][r], v1 = acc[m][g][py * 2 + 1][r] * dm[m][r];
+            const float v0 = acc[m][g][py * 2][r] * dm_m[r], v1 = acc[m][g][py * 2 + 1][r] * dm_m[r];
             if (pair) {
               f32x2_u t; t.x = v0; t.y = v1;
               *reinterpret_cast<f32x2_u*>(dst + (long long)py * drs) = t;
@@ -508,6 +678,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
             }
           }
         }
+      }
     }
   }
   if constexpr (RGB) {
@@ -616,33 +787,66 @@ inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
   return (long long)sg.tiles_x * sg.tiles_y * sg.tiles_b;
 }
 
-template <int MODE, int RM, int RNP, int WM, int WN, int MINB = 2>
+constexpr size_t MC_LDS_LIMIT = 64 * 1024;   // dynamic LDS a launch may ask for without a function attribute
+
+// Returns FMGAN_OK, an error, or +1 when this variant cannot serve the shape (PIPE 1 with an LDS image over the limit):
+// the caller then launches the register-pipeline variant.
+template <int MODE, int RM, int RNP, int WM, int WN, int MINB = 2, int KC = MC_KC, int PIPE = 0>
 int launch_cfg(MCParams& p, hipStream_t s) {
   if constexpr (MODE != 0) { if (p.rgb_out) return FMGAN_EUNSUPPORTED; }
   constexpr int BM = 32 * RM * WM, BN = 32 * RNP * WN;
   constexpr int SP = MODE == 2 ? 2 : 1;
   p.o_tiles = (p.cout + BM - 1) / BM;
   long long blocks = 0;
-  size_t patch = 0;
+  size_t patch = 0, nbmax = 1;
   for (int i = 0; i < p.nseg; ++i) {
     blocks += plan_segment(p.seg[i], p.batch, BN) * p.o_tiles;
     if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
     p.seg[i].block_end = (unsigned)blocks;
-    // 32-bit in-tile element offsets: (nb samples) x cin x h x w must fit
-    if ((long long)p.seg[i].nb * p.cin * p.h * p.w >= (1LL << 31)) return FMGAN_EOVERFLOW;
-    const size_t f = (size_t)p.seg[i].nb * MC_KC * (SP * (p.seg[i].th - 1) + 3) * (SP * ((1 << p.seg[i].tw_log2) - 1) + 3);
+    // 32-bit in-tile element offsets: (samples of a tile that exist) x cin x h x w must fit.  (Slots of a tile's
+    // samples beyond the batch are never addressed: their offsets are parked / their loads masked.)
+    const int nb_live = p.seg[i].nb < p.batch ? p.seg[i].nb : p.batch;
+    if ((long long)nb_live * p.cin * p.h * p.w >= (1LL << 31)) return FMGAN_EOVERFLOW;
+    const size_t f = (size_t)p.seg[i].nb * KC * (SP * (p.seg[i].th - 1) + 3) * (SP * ((1 << p.seg[i].tw_log2) - 1) + 3);
     if (f > patch) patch = f;
+    if ((size_t)p.seg[i].nb > nbmax) nbmax = p.seg[i].nb;
   }
-  const size_t lds = sizeof(float) * ((size_t)MC_KC * 9 * BM + patch);
+  size_t lds = sizeof(float) * ((size_t)KC * 9 * BM + patch);
+  if constexpr (PIPE == 1) {
+    if (p.cin_per_split % KC != 0) return 1;
+    p.lds_patch_floats = (int)((patch + 63) / 64 * 64);
+    p.lds_buf_floats = KC * 9 * BM + p.lds_patch_floats + (int)((nbmax * KC + 63) / 64 * 64);
+    lds = sizeof(float) * 2 * (size_t)p.lds_buf_floats;
+    if (lds > MC_LDS_LIMIT) return 1;
+  }
   if constexpr (MODE == 0) {
     if (p.rgb_out) {
       if (p.o_tiles != 1 || p.ksplit != 1) return FMGAN_EUNSUPPORTED;
-      hipLaunchKernelGGL((modconv_mfma_f32<0, RM, RNP, WM, WN, true, MINB>), dim3((unsigned)blocks, 1), dim3(256), lds, s, p);
+      hipLaunchKernelGGL((modconv_mfma_f32<0, RM, RNP, WM, WN, true, MINB, KC, PIPE>), dim3((unsigned)blocks, 1), dim3(256), lds, s, p);
       return fmgan_check_launch();
     }
   }
-  hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RNP, WM, WN, false, MINB>), dim3((unsigned)blocks, p.ksplit), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((modconv_mfma_f32<MODE, RM, RNP, WM, WN, false, MINB, KC, PIPE>), dim3((unsigned)blocks, p.ksplit), dim3(256), lds, s, p);
   return fmgan_check_launch();
+}
+
+// Which pipeline variant serves (mode, cfg): 'A' = register prefetch, 'B'/'C' = LDS-DMA variants.  Defaults are the
+// measured winners (profiles/r02_modconv_variants.md); FMGAN_MC_V<mode><cfg>=A|B|C overrides one entry (experiments).
+inline char mc_variant(int mode, int cfg) {
+  static char table[3][3];
+  static bool init = false;
+  if (!init) {
+    const char defaults[3][3] = {{'A', 'A', 'A'}, {'A', 'A', 'A'}, {'A', 'A', 'A'}};
+    for (int m = 0; m < 3; ++m)
+      for (int c = 0; c < 3; ++c) {
+        char name[32];
+        snprintf(name, sizeof(name), "FMGAN_MC_V%d%d", m, c);
+        const char* e = getenv(name);
+        table[m][c] = (e && (e[0] == 'A' || e[0] == 'B' || e[0] == 'C')) ? e[0] : defaults[m][c];
+      }
+    init = true;
+  }
+  return table[mode][cfg];
 }
 
 // Tile configurations (output channels x positions per block; blocks per CU the register budget allows):
@@ -675,11 +879,21 @@ inline int cfg_blocks_per_cu(int mode, int cfg) {
 }
 
 inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
+  const char v = mc_variant(mode, cfg);
+  int st = 1;
   if (mode == 0) {
     switch (cfg) {
-      case 0: return launch_cfg<0, 2, 2, 2, 2>(p, s);
-      case 1: return launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
-      default: return launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
+      case 0:
+        if (v == 'B') st = launch_cfg<0, 2, 2, 2, 2, 3, 4, 1>(p, s);
+        else if (v == 'C') st = launch_cfg<0, 2, 2, 2, 2, 2, 4, 1>(p, s);
+        return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
+      case 1:
+        if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);
+        return st != 1 ? st : launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
+      default:
+        if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
+        else if (v == 'C') st = launch_cfg<0, 1, 1, 1, 4, 3, 16, 1>(p, s);
+        return st != 1 ? st : launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
     }
   }
   if (mode == 2) {
@@ -689,7 +903,13 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
       default: return launch_cfg<2, 1, 1, 1, 4>(p, s);
     }
   }
-  return cfg == 1 ? launch_cfg<1, 2, 1, 1, 4>(p, s) : launch_cfg<1, 1, 1, 1, 4, 3>(p, s);
+  if (cfg == 1) {
+    if (v == 'B') st = launch_cfg<1, 2, 1, 1, 4, 2, 8, 1>(p, s);
+    return st != 1 ? st : launch_cfg<1, 2, 1, 1, 4>(p, s);
+  }
+  if (v == 'B') st = launch_cfg<1, 1, 1, 1, 4, 3, 8, 1>(p, s);
+  else if (v == 'C') st = launch_cfg<1, 1, 1, 1, 4, 2, 16, 1>(p, s);
+  return st != 1 ? st : launch_cfg<1, 1, 1, 1, 4, 3>(p, s);
 }
 
 // Blocks of one launch (all segments), for a given tile configuration.

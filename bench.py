@@ -47,6 +47,15 @@ WORKLOADS = {
 }
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (rank 0): the JSON line on stdout stays alone, and a long run is never silent."""
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(f'[bench {time.time() - _T0:6.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 class LaunchTimer:
     """HIP events on the launch stream (torch's current stream IS the stream _native launches on) around the
     launches selected by `want`; times are read after the region has been synchronised."""
@@ -260,6 +269,7 @@ def cpu_baseline_items(sds, photo, render, size):
     import math
     from oracle import torch_oracle as T
     items = {}
+    log('cpu baseline items')
     with torch.no_grad():
         # ops at the headline shapes, B=1
         x = torch.randn(1, 32, 1025, 1025)
@@ -367,6 +377,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl['batch']
+    log(f'building models for {args.workload}')
     nets = build_models(wl['size'], device)
     if args.workload.startswith('train'):
         if args.workload == 'train256':
@@ -375,7 +386,11 @@ def main():
             for m in nets.values():
                 m.requires_grad_(True)
             step, _ = make_trainstep(nets, batch, device, rank, world, wl['size'])
-        dt = timed(step, args.steps, args.warmup, world)
+        for i in range(args.warmup):
+            step()
+            torch.cuda.synchronize()
+            log(f'{args.workload}: warm-up step {i + 1}/{args.warmup} done')
+        dt = timed(step, args.steps, 0, world)
         if rank == 0:
             print(json.dumps({
                 'metric': '(photo,render) pairs/sec (forward+backward)' if args.workload == 'train256' else
@@ -395,8 +410,10 @@ def main():
     r = wl['size']
     head = (batch * nets['g'].channels[r], r + 1, r + 1, r, r, 1, 1, 4)
     timer = LaunchTimer(lambda name, info: name == 'upfirdn2d' and info == head)
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f'warm-up step {i + 1}/{args.warmup} done')
     _native.set_observer(timer)
     dt_eager = timed(step, args.steps, 0, world)      # eager launches; the headline kernel is bracketed by HIP events
     _native.set_observer(None)
@@ -407,6 +424,7 @@ def main():
         graphed = GraphedForward(step.forward, inputs)
         dt = timed(lambda: graphed(*inputs), args.steps, 2, world)   # the same forward, replayed as one HIP graph
     pairs_per_s = world * batch * args.steps / dt
+    log(f'{args.workload}: {pairs_per_s:.1f} pairs/s')
 
     out = {
         'metric': '(photo,render) pairs/sec', 'value': pairs_per_s, 'unit': 'pairs/s', 'n_gpus': world,
@@ -496,6 +514,7 @@ def main():
             g2 = GraphedForward(step2.forward, in2)
             dt2 = timed(lambda: g2(*in2), args.steps, 2, world)
             del g2
+        log('pairs256 done')
         out['pairs_per_s_256'] = world * wl2['batch'] * args.steps / dt2
         out['ms_per_step_256'] = 1e3 * dt2 / args.steps
         out['config']['secondary'] = f"pairs256: {wl2['desc']}"
@@ -528,7 +547,12 @@ def main():
                     step_t, _ = make_train_step(nets_t, wt['batch'], device, rank, world)
                 else:
                     step_t, _ = make_trainstep(nets_t, wt['batch'], device, rank, world, wt['size'])
-                dt_t = timed(step_t, t_steps, t_warm, world)
+                for i in range(t_warm):          # (MIOpen builds its backward kernels on first use: log every step)
+                    step_t()
+                    torch.cuda.synchronize()
+                    log(f'{name}: warm-up step {i + 1}/{t_warm} done')
+                dt_t = timed(step_t, t_steps, 0, world)
+                log(f'{name}: {world * wt["batch"] * t_steps / dt_t:.1f} pairs/s')
                 out[name + '_pairs_per_s'] = world * wt['batch'] * t_steps / dt_t
                 out[name + '_ms_per_step'] = 1e3 * dt_t / t_steps
                 out['config'][name] = f"{wt['desc']} ({t_steps} timed steps)"
@@ -539,7 +563,9 @@ def main():
 
     del graphed
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('cpu baseline (bounded sample of the CPU path)')
         out['cpu_baseline'] = cpu_baseline(nets, inputs, wl['size'])
+        log('cpu baseline done')
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
