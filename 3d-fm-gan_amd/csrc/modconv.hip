@@ -25,6 +25,18 @@
 
 namespace {
 
+// LDS-DMA: `buffer_load_dword(x4) ... lds` — 64 lanes x SIZE bytes land at lds + lane * SIZE (wave-uniform base), from
+// rsrc base + voff (per lane, range-checked against the resource: out of range -> zeros) + soff (wave-uniform).
+// (Kept in a helper with a device-pass guard: the host pass of hipcc silently drops the host stub of a template
+// kernel whose body names this builtin directly.)
+template <int SIZE, typename RSRC>
+__device__ __forceinline__ void dma_to_lds(RSRC rsrc, float* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) void* lds_void_ptr;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)lds, SIZE, voff, soff, 0, 0);
+#endif
+}
+
 // ------------------------------------------------------------------ demod
 // PRE: W is the per-(o,i) sum of squared taps [cout][cin] (modconv_wsq_f32, cached with the weight) instead of the
 // raw weight — the same fma chains in the same order, so both variants give identical bits.
@@ -485,7 +497,6 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       contract();
     }
   } else {
-    typedef __attribute__((address_space(3))) void* lds_void_ptr;
     constexpr unsigned PARKED = 0xFFFFFFF0u;
     constexpr int WSZ = KC * 9 * BM;                        // floats of one weight image
     constexpr int WPIECES = WSZ / 256;                      // 16-byte pieces (64 lanes x 16 B = 256 floats)
@@ -534,17 +545,17 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
 #pragma unroll
         for (int j = 0; j < NWP; ++j)
           if (4 * j + wave < WPIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_ptr)(Wb + (4 * j + wave) * 256), 16, wvo[j], soff_w, 0, 0);
+            dma_to_lds<16>(rsrc_w, Wb + (4 * j + wave) * 256, wvo[j], soff_w);
 #pragma unroll
         for (int u = 0; u < NUP; ++u)
           if (4 * u + wave < x_pieces)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_void_ptr)(Xb + (4 * u + wave) * 64), 4, xvo[u], soff_x, 0, 0);
+            dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[u], soff_x);
         for (int pc = 4 * NUP + wave; pc < x_pieces; pc += 4)       // patches larger than a main tile's
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_void_ptr)(Xb + pc * 64), 4, x_voff(pc * 64 + lane), soff_x, 0, 0);
+          dma_to_lds<4>(rsrc_x, Xb + pc * 64, x_voff(pc * 64 + lane), soff_x);
         if (wave < s_pieces)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_void_ptr)(Sb + wave * 64), 4, svo, (unsigned)(i0 * 4), 0, 0);
+          dma_to_lds<4>(rsrc_s, Sb + wave * 64, svo, (unsigned)(i0 * 4));
         for (int pc = 4 + wave; pc < s_pieces; pc += 4)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_void_ptr)(Sb + pc * 64), 4, s_voff(pc * 64 + lane), (unsigned)(i0 * 4), 0, 0);
+          dma_to_lds<4>(rsrc_s, Sb + pc * 64, s_voff(pc * 64 + lane), (unsigned)(i0 * 4));
       } else {
         // guarded synchronous fill (same images, zeros where the DMA's range check would have produced them)
         for (int idx = tid; idx < KC * 9 * (BM / 4); idx += 256) {
