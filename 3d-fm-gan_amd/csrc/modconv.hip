@@ -146,6 +146,10 @@ struct MCParams {
   // PIPE 1 (all staging by LDS-DMA): floats per LDS buffer = weights + patch region + style region, and the patch
   // region's size (both rounded to 64 floats so every DMA piece of 64 lanes x 4 B stays inside its region)
   int lds_buf_floats, lds_patch_floats;
+  // experiments only (FMGAN_MC_DEBUG, tools/bench_conv_variants.py --debug): bit 0 = stage the first chunk only (ablation:
+  // what the MFMA + operand-fetch loop alone reaches; results are wrong), bit 1 = no barriers in the K loop (wrong too),
+  // bit 2 = PIPE 1: issue all DMA pieces of the next chunk up front instead of spreading them over the MFMA stages.
+  int debug;
 };
 
 constexpr int MC_KC = 8;  // input channels per LDS chunk
@@ -462,12 +466,14 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // ---- contract: operands of stage st+1 are fetched while stage st is on the matrix pipe.
   // (hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) in front of each group of four:
   // the sched_barriers keep "issue all reads of stage st+1, then run stage st's MFMAs" as written.)
-  auto contract = [&]() {
+  // hook(st): extra issue work placed in front of stage st's MFMAs (PIPE 1: a slice of the next chunk's DMA pieces)
+  auto contract = [&](auto&& hook) {
     Ops cur, nxt;
     fetch(cur, 0);
 #pragma unroll
     for (int st = 0; st < NSTAGE; ++st) {
       __builtin_amdgcn_sched_barrier(0);
+      hook(st);
       if (st + 1 < NSTAGE) {
         fetch(nxt, st + 1);
         if constexpr (PIPE == 1 && MODE != 1) {
@@ -489,12 +495,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   if constexpr (PIPE == 0) {
     if (i_begin < i_end) issue(i_begin);
     for (int i0 = i_begin; i0 < i_end; i0 += KC) {
-      __syncthreads();            // every wave is done reading the previous chunk
-      commit(i0);
-      __syncthreads();
+      const bool live = !(p.debug & 1) || i0 == i_begin;
+      if (!(p.debug & 2)) __syncthreads();            // every wave is done reading the previous chunk
+      if (live) commit(i0);
+      if (!(p.debug & 2)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      if (i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
-      contract();
+      if (live && i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
+      contract([](int) {});
     }
   } else {
     constexpr unsigned PARKED = 0xFFFFFFF0u;
@@ -535,27 +542,40 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     for (int u = 0; u < NUP; ++u) xvo[u] = x_voff((4 * u + wave) * 64 + lane);
     const unsigned svo = s_voff(wave * 64 + lane);          // first style piece of this wave (all of them when nb*KC <= 256)
 
-    auto stage = [&](int i0, int buf) {
+    // This wave's DMA pieces of one chunk, numbered k = 0 .. NPC-1: weights, patch, then the style slice together with
+    // whatever a larger-than-main-tile patch / a sample-packed style slice has left.
+    constexpr int NPC = NWP + NUP + 1;
+    constexpr int PER_STAGE = (NPC + NSTAGE - 1) / NSTAGE;
+    auto dma_piece = [&](int k, int i0, int buf) {
       float* Wb = smem + buf * bstride;
       float* Xb = Wb + WSZ;
-      float* Sb = Xb + p.lds_patch_floats;
-      if (fastc && i0 + KC <= i_end) {
-        const unsigned soff_w = (unsigned)(i0 * 9 * p.cout * 4);
-        const unsigned soff_x = (unsigned)(i0 * hw * 4);
-#pragma unroll
-        for (int j = 0; j < NWP; ++j)
-          if (4 * j + wave < WPIECES)
-            dma_to_lds<16>(rsrc_w, Wb + (4 * j + wave) * 256, wvo[j], soff_w);
-#pragma unroll
-        for (int u = 0; u < NUP; ++u)
-          if (4 * u + wave < x_pieces)
-            dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[u], soff_x);
+      const unsigned soff_x = (unsigned)(i0 * hw * 4);
+      if (k < NWP) {
+        if (4 * k + wave < WPIECES)
+          dma_to_lds<16>(rsrc_w, Wb + (4 * k + wave) * 256, wvo[k < NWP ? k : 0], (unsigned)(i0 * 9 * p.cout * 4));
+      } else if (k < NWP + NUP) {
+        const int u = k - NWP;
+        if (4 * u + wave < x_pieces)
+          dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], soff_x);
+      } else {
+        float* Sb = Xb + p.lds_patch_floats;
         for (int pc = 4 * NUP + wave; pc < x_pieces; pc += 4)       // patches larger than a main tile's
           dma_to_lds<4>(rsrc_x, Xb + pc * 64, x_voff(pc * 64 + lane), soff_x);
         if (wave < s_pieces)
           dma_to_lds<4>(rsrc_s, Sb + wave * 64, svo, (unsigned)(i0 * 4));
         for (int pc = 4 + wave; pc < s_pieces; pc += 4)
           dma_to_lds<4>(rsrc_s, Sb + pc * 64, s_voff(pc * 64 + lane), (unsigned)(i0 * 4));
+      }
+    };
+    auto dma_ok = [&](int i0) { return fastc && i0 + KC <= i_end; };
+
+    auto stage = [&](int i0, int buf) {
+      float* Wb = smem + buf * bstride;
+      float* Xb = Wb + WSZ;
+      float* Sb = Xb + p.lds_patch_floats;
+      if (dma_ok(i0)) {
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) dma_piece(k, i0, buf);
       } else {
         // guarded synchronous fill (same images, zeros where the DMA's range check would have produced them)
         for (int idx = tid; idx < KC * 9 * (BM / 4); idx += 256) {
@@ -596,14 +616,25 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       // this wave's DMA pieces / LDS stores of chunk i0 have landed; after the barrier everyone's have, and every wave
       // has finished reading the other buffer (its ds_reads were retired before the MFMAs that consumed them)
       __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_s_barrier();
+      if (!(p.debug & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (i0 + KC < i_end) stage(i0 + KC, buf ^ 1);
+      const int i1 = i0 + KC;
+      const bool more = i1 < i_end && !(p.debug & 1);
+      // the next chunk's pieces: spread over this chunk's MFMA stages (each DMA issue then hides behind a matrix
+      // instruction of the same wave), or all at once for a chunk the DMA cannot serve / with debug bit 2
+      const bool spread = more && dma_ok(i1) && !(p.debug & 4);
+      if (more && !spread) stage(i1, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       Wc = smem + buf * bstride;
       Xc = Wc + WSZ;
       Sc = Xc + p.lds_patch_floats;
-      contract();
+      contract([&](int st) {
+        if (spread) {
+#pragma unroll
+          for (int q = 0; q < PER_STAGE; ++q)
+            if (st * PER_STAGE + q < NPC) dma_piece(st * PER_STAGE + q, i1, buf ^ 1);
+        }
+      });
     }
   }
 
@@ -1309,6 +1340,11 @@ int modconv2d_impl(const float* in, const float* wt, const float* style, const f
   if (rgb && (!rgb->wmod || !rgb->out)) return FMGAN_EINVAL;
   if (fuse_act && noise && noise_batch != 1 && noise_batch != batch) return FMGAN_EINVAL;
   MCParams p{};
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("FMGAN_MC_DEBUG"); dbg = e ? atoi(e) : 0; }
+    p.debug = dbg;
+  }
   if (rgb) {
     p.rgb_wmod = rgb->wmod; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip; p.rgb_out = rgb->out; p.rgb_c = rgb->c;
   }

@@ -2,12 +2,14 @@
 
 Forward runs on the hand-written MFMA kernels.  The reference gets its gradients (to second order: path-length
 regularisation differentiates through Generator.forward with create_graph=True, stylegan2.py:683-688) from
-autograd over F.conv2d / F.conv_transpose2d.  Here the backward re-states the same op as a differentiable
-composite of PyTorch-ROCm ops *in the input-modulated form* (dense convs with batch-shared weights, no
-[B*Cout,Cin,3,3] weight materialisation) and lets autograd differentiate that, so any derivative order works.
-Without a requested graph (plain loss.backward()) the data gradient runs on the MFMA kernel itself
-(ModulatedConv2dFunction.backward): 3 convolutions per layer per training step instead of the 4 of
-"HIP forward + recomputed composite".
+autograd over F.conv2d / F.conv_transpose2d.  Here:
+  * plain loss.backward() (no graph requested): the data gradient runs on the MFMA kernel itself with swapped roles
+    (ModulatedConv2dFunction.backward): 3 convolutions per layer per training step;
+  * create_graph=True: the backward re-states the op in the input-modulated form  d (.) C(x (.) s, scale W)  whose
+    dense contraction C is the DenseConv / DenseConvDgrad / DenseConvWgrad family — three autograd Functions on the
+    MFMA kernel that differentiate into each other (the way the reference nests UpFirDn2d / UpFirDn2dBackward,
+    op/upfirdn2d.py:28-94), so every derivative order runs this repo's kernels; only the weight-gradient primitive
+    is MIOpen's wgrad unless FMGAN_HIP_WGRAD=1.
 """
 import os
 
@@ -20,6 +22,7 @@ from . import _native
 # Weight gradient of the plain conv: MIOpen's fp32 wgrad measures 105-112 TFLOP/s on MI355X, this repo's
 # fmgan_modconv_wgrad_f32 50 TFLOP/s (synchronous staging; bit-reproducible) — MIOpen is the default.
 HIP_WGRAD = os.environ.get('FMGAN_HIP_WGRAD', '0') == '1'
+COMPOSITE_MIOPEN = os.environ.get('FMGAN_COMPOSITE_MIOPEN', '0') == '1'
 
 
 def modconv_composite(x, weight, s, demodulate, mode, scale, eps=1e-8):
@@ -35,6 +38,114 @@ def modconv_composite(x, weight, s, demodulate, mode, scale, eps=1e-8):
         y = F.conv2d(xs, w, stride=2)
     else:
         y = F.conv2d(xs, w, padding=k // 2)
+    if demodulate:
+        d = torch.rsqrt(s.pow(2) @ w.pow(2).sum([2, 3]).t() + eps)
+        y = y * d[:, :, None, None]
+    return y
+
+
+# ----------------------------------------------------------------------------- dense 3x3 convs, closed under d/d.
+# The reference gets every derivative order by nesting autograd Functions whose backward is the same native op again
+# (op/upfirdn2d.py:28-94).  The modulated conv is  y = d (.) C(x (.) s, scale W)  with C a dense, batch-shared 3x3
+# convolution; C is bilinear in (input, weight), and its two adjoints are again such convolutions:
+#     C_m(u, W)       forward             mode 0 pad-1 | mode 1 transposed stride 2 | mode 2 stride-2 valid
+#     D_m(g, W)       adjoint w.r.t. u    mode 0: C_0 with W^T flipped | mode 1: C_2 with W^T | mode 2: C_1 with W^T
+#     G_m(u, g)       adjoint w.r.t. W    (weight gradient)
+# and   dD_m/dg = C_m(., W),  dD_m/dW = G_m(., g),  dG_m/du = D_m(g, .),  dG_m/dg = C_m(u, .)
+# — three Functions that differentiate into each other, so R1 / path-length regularisation (create_graph=True) run
+# on the MFMA kernel at every order.  Modulation and demodulation stay elementwise torch ops around C.
+_ONES = {}
+
+
+def _ones(batch, ch, device):
+    key = (batch, ch, device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(batch, ch, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+def _kernel_conv(u, w4, mode, kind):
+    """The MFMA kernel as a dense conv: channels contracted = w4's dim 1 (kind 0) or dim 0 (kinds 1, 2)."""
+    wt = _native.modconv_weight_prep(w4, 1.0, kind=kind)
+    return _native.modconv2d(u, wt, _ones(u.shape[0], u.shape[1], u.device), None, mode)
+
+
+def _wgrad(u, g, mode):
+    """G_m(u, g) -> [cout, cin, 3, 3].  mode 0 on this repo's MFMA wgrad kernel when enabled, else MIOpen's fp32 wgrad."""
+    cout, cin = g.shape[1], u.shape[1]
+    if mode == 0:
+        gw = _native.modconv_wgrad(g, None, u, _ones(u.shape[0], cin, u.device), 1.0) if HIP_WGRAD else None
+        return gw if gw is not None else torch.nn.grad.conv2d_weight(u, (cout, cin, 3, 3), g, padding=1)
+    if mode == 1:   # y = conv_transpose2d(u, W^T, stride 2): adjoint of conv2d(., W^T, stride 2)
+        return torch.nn.grad.conv2d_weight(g, (cin, cout, 3, 3), u, stride=2).transpose(0, 1)
+    return torch.nn.grad.conv2d_weight(u, (cout, cin, 3, 3), g, stride=2)
+
+
+_ADJ = {0: (0, 1), 1: (2, 2), 2: (1, 2)}      # mode -> (kernel mode, weight layout kind) of D_m
+
+
+class DenseConv(Function):
+    """C_m(u, W): u [B,Cin,H,W] f32, W [Cout,Cin,3,3]."""
+
+    @staticmethod
+    def forward(ctx, u, w4, mode):
+        ctx.save_for_backward(u, w4)
+        ctx.mode = mode
+        return _kernel_conv(u.contiguous(), w4, mode, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, w4 = ctx.saved_tensors
+        gu = DenseConvDgrad.apply(g, w4, ctx.mode, tuple(u.shape[2:])) if ctx.needs_input_grad[0] else None
+        gw = DenseConvWgrad.apply(u, g, ctx.mode) if ctx.needs_input_grad[1] else None
+        return gu, gw, None
+
+
+class DenseConvDgrad(Function):
+    """D_m(g, W): the adjoint of C_m(., W), again on the MFMA kernel (roles of Cin / Cout swapped)."""
+
+    @staticmethod
+    def forward(ctx, g, w4, mode, in_hw):
+        ctx.save_for_backward(g, w4)
+        ctx.mode = mode
+        km, kind = _ADJ[mode]
+        out = _kernel_conv(g.contiguous(), w4, km, kind)
+        if mode == 2 and tuple(out.shape[2:]) != tuple(in_hw):
+            # a stride-2 valid conv ignores the last row/column of an even-sized input: their gradient is zero
+            out = F.pad(out, (0, in_hw[1] - out.shape[3], 0, in_hw[0] - out.shape[2]))
+        return out
+
+    @staticmethod
+    def backward(ctx, h):
+        g, w4 = ctx.saved_tensors
+        gg = DenseConv.apply(h, w4, ctx.mode) if ctx.needs_input_grad[0] else None
+        gw = DenseConvWgrad.apply(h, g, ctx.mode) if ctx.needs_input_grad[1] else None
+        return gg, gw, None, None
+
+
+class DenseConvWgrad(Function):
+    """G_m(u, g): weight gradient of C_m."""
+
+    @staticmethod
+    def forward(ctx, u, g, mode):
+        ctx.save_for_backward(u, g)
+        ctx.mode = mode
+        return _wgrad(u.contiguous(), g.contiguous(), mode).contiguous()
+
+    @staticmethod
+    def backward(ctx, hw):
+        u, g = ctx.saved_tensors
+        hw = hw.contiguous()
+        gu = DenseConvDgrad.apply(g, hw, ctx.mode, tuple(u.shape[2:])) if ctx.needs_input_grad[0] else None
+        gg = DenseConv.apply(u, hw, ctx.mode) if ctx.needs_input_grad[1] else None
+        return gu, gg, None
+
+
+def modconv_composite_hip(x, weight, s, demodulate, mode, scale, eps=1e-8):
+    """modconv_composite with the contraction on the MFMA kernel at every derivative order (float32, 3x3)."""
+    cout, cin, k, _ = weight.shape[-4:]
+    w = weight.reshape(cout, cin, k, k) * scale
+    y = DenseConv.apply(x * s[:, :, None, None], w, mode)
     if demodulate:
         d = torch.rsqrt(s.pow(2) @ w.pow(2).sum([2, 3]).t() + eps)
         y = y * d[:, :, None, None]
@@ -80,8 +191,10 @@ class ModulatedConv2dFunction(Function):
         x, weight, s = ctx.saved_tensors[:3]
         need = ctx.needs_input_grad[:3]
         if torch.is_grad_enabled() or mode == 2 or grad_out.dtype != torch.float32:
-            gx, gw, gs = _regrad(lambda a, b, c: modconv_composite(a, b, c, demodulate, mode, scale), (x, weight, s),
-                                 need, grad_out)
+            # a graph is wanted (R1 / path-length regularisation): differentiate the composite whose contraction is
+            # the DenseConv family above — HIP kernels at every order (FMGAN_COMPOSITE_MIOPEN=1: the all-MIOpen form)
+            comp = modconv_composite if (COMPOSITE_MIOPEN or grad_out.dtype != torch.float32) else modconv_composite_hip
+            gx, gw, gs = _regrad(lambda a, b, c: comp(a, b, c, demodulate, mode, scale), (x, weight, s), need, grad_out)
             return gx, gw, gs, None, None, None, None
         go = grad_out.contiguous()
         cout, cin, k, _ = weight.shape[-4:]

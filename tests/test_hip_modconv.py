@@ -406,3 +406,77 @@ def test_guard_boundary_shapes_compute_correctly(cfg):
     assert torch.isfinite(y[:, :, ::997, ::991]).all()
     del y, xd
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------- nested dense-conv Functions
+@pytest.mark.parametrize('cfg', [
+    # (mode, b, cin, cout, h, w)
+    (0, 2, 6, 10, 9, 7), (1, 2, 6, 10, 5, 6), (2, 2, 6, 10, 9, 11), (2, 1, 5, 7, 8, 10), (0, 1, 40, 24, 20, 20),
+    (1, 3, 12, 33, 8, 8),
+])
+def test_dense_conv_family_differentiates_into_itself(cfg):
+    """op.modconv.DenseConv / DenseConvDgrad / DenseConvWgrad (the create_graph=True path of ModulatedConv2d) against
+    float64 autograd over torch's functional convs on the CPU: first, second and third derivatives, every mode (mode 2
+    with an even-sized input, whose last row/column the stride-2 valid conv never reads)."""
+    from op import modconv
+    import torch.nn.functional as F
+    mode, b, cin, cout, h, w = cfg
+    u = synth.tensor(f'dcf/{cfg}/u', (b, cin, h, w))
+    wt = synth.tensor(f'dcf/{cfg}/w', (cout, cin, 3, 3), scale=0.3)
+
+    def ref_conv(uu, ww):
+        if mode == 0:
+            return F.conv2d(uu, ww, padding=1)
+        if mode == 1:
+            return F.conv_transpose2d(uu, ww.transpose(0, 1), stride=2)
+        return F.conv2d(uu, ww, stride=2)
+
+    def chain(conv, uu, ww, dt, device):
+        y = conv(uu, ww)
+        g1 = synth.tensor(f'dcf/{cfg}/g1', y.shape).to(device=device, dtype=dt)
+        gu, gw = torch.autograd.grad(y, (uu, ww), g1, create_graph=True)
+        l2 = (gu.pow(2).sum() + (gw * gw.detach().roll(1, 0)).sum())                 # uses D_m and G_m
+        hu, hw = torch.autograd.grad(l2, (uu, ww), create_graph=True)                # their derivatives: C, D, G again
+        l3 = hu.pow(2).mean() + hw.pow(2).mean()
+        tu, tw = torch.autograd.grad(l3, (uu, ww))                                   # third order
+        return [t.detach().cpu().double().numpy() for t in (y, gu, gw, hu, hw, tu, tw)]
+
+    ro = chain(ref_conv, u.double().requires_grad_(True), wt.double().requires_grad_(True), torch.float64, 'cpu')
+    rd = chain(lambda a, c: modconv.DenseConv.apply(a, c, mode), u.to(dev()).requires_grad_(True),
+               wt.to(dev()).requires_grad_(True), torch.float32, dev())
+    for name, a, r, k in zip('y gu gw hu hw tu tw'.split(), rd, ro, (2e-5, 2e-5, 5e-5, 1e-4, 1e-4, 5e-4, 5e-4)):
+        np.testing.assert_allclose(a, r, atol=k * max(1e-6, float(np.abs(r).max())), rtol=k * 10, err_msg=name)
+
+
+def test_create_graph_path_runs_on_hip_kernels():
+    """With a graph requested, ModulatedConv2d's backward must go through the DenseConv family (this repo's kernel),
+    not through F.conv2d: count the MFMA-kernel launches the observer sees during backward + double backward."""
+    import stylegan2
+    from op import _native
+
+    class Count:
+        def __init__(self):
+            self.n = {}
+
+        def begin(self, name, info):
+            self.n[name] = self.n.get(name, 0) + 1
+            return None
+
+        def end(self, tok):
+            pass
+
+    m = _load(stylegan2.StyledConv(6, 10, 3, 512, upsample=True), 'generator', 11)
+    x = synth.tensor('cgp/x', (2, 6, 5, 5)).to(dev()).requires_grad_(True)
+    w = synth.tensor('cgp/w', (2, 512)).to(dev()).requires_grad_(True)
+    y = m(x, w, noise=synth.tensor('cgp/n', (2, 1, 10, 10)).to(dev()))
+    obs = Count()
+    _native.set_observer(obs)
+    try:
+        gx, = torch.autograd.grad(y.sum(), x, create_graph=True)
+        first = obs.n.get('modconv2d', 0)
+        gx.pow(2).sum().backward()
+        second = obs.n.get('modconv2d', 0) - first
+    finally:
+        _native.set_observer(None)
+    assert first >= 2, obs.n       # recomputed forward C + data gradient D on the MFMA kernel
+    assert second >= 2, obs.n      # their derivatives, again on the MFMA kernel

@@ -49,6 +49,16 @@ def main():
     batch = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 8
     if '--worker' in sys.argv:
         return worker(batch)
+    if '--debug' in sys.argv:       # ablations (FMGAN_MC_DEBUG bits, csrc/modconv.hip MCParams::debug); results are not valid outputs
+        for dbg in sys.argv[sys.argv.index('--debug') + 1].split(','):
+            print(f'\n## FMGAN_MC_DEBUG={dbg}\n')
+            os.environ['FMGAN_MC_DEBUG'] = dbg
+            table(batch)
+        return
+    table(batch)
+
+
+def table(batch):
     res = {}
     for v in 'ABC':
         env = dict(os.environ)
