@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   int si = 0;
   while (si + 1 < p.nseg && lb >= p.seg[si].block_end) ++si;
   if (si > 0) lb -= p.seg[si - 1].block_end;
+  const int thin = (MODE == 1 && p.nseg == 3) ? (si == 0 ? 1 : (si == 1 ? 2 : 0)) : 0;   // mode 1: row / column strip
   const int seg_th = p.seg[si].th, seg_nb = p.seg[si].nb, tw_log2 = p.seg[si].tw_log2;
   const int seg_m_end = p.seg[si].m_off + p.seg[si].gh, seg_n_end = p.seg[si].n_off + p.seg[si].gw;
   constexpr int SP = MODE == 2 ? 2 : 1;          // input step per position
@@ -452,14 +453,23 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     } else {
       // (tap = ky*3+kx, input-offset index j, phase = py*2+px)
       constexpr int T[9][3] = {{0, 0, 0}, {2, 1, 0}, {6, 2, 0}, {8, 3, 0}, {1, 0, 1}, {7, 2, 1}, {3, 0, 2}, {5, 1, 2}, {4, 0, 3}};
+      auto run = [&](auto keep) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q)
+        for (int q = 0; q < 9; ++q)
+          if (keep(T[q][0]))
 #pragma unroll
-        for (int m = 0; m < RM; ++m)
+            for (int m = 0; m < RM; ++m)
 #pragma unroll
-          for (int g = 0; g < RNP; ++g)
-            acc[m][g][T[q][2]] =
-                __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[T[q][0]][m], o.b[T[q][1]][g], acc[m][g][T[q][2]], 0, 0, 0);
+              for (int g = 0; g < RNP; ++g)
+                acc[m][g][T[q][2]] =
+                    __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[T[q][0]][m], o.b[T[q][1]][g], acc[m][g][T[q][2]], 0, 0, 0);
+      };
+      // The two thin segments (last output row: positions m = h; last output column: n = w) only ever see the taps
+      // whose input lies inside the image — ky = 2 resp. kx = 2: every other product has a zero operand.  Their
+      // blocks issue 3 of the 9 MFMAs per channel pair (same sums, bit for bit) and finish three times sooner.
+      if (thin == 0) run([](int) { return true; });
+      else if (thin == 1) run([](int tap) { return tap / 3 == 2; });
+      else run([](int tap) { return tap % 3 == 2; });
     }
   };
 
@@ -927,14 +937,15 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
     switch (cfg) {
       case 0:
         if (v == 'B') st = launch_cfg<0, 2, 2, 2, 2, 3, 4, 1>(p, s);
-        else if (v == 'C') st = launch_cfg<0, 2, 2, 2, 2, 2, 4, 1>(p, s);
+        else if (v == 'C' && !p.rgb_out) st = launch_cfg<0, 2, 2, 1, 4, 2, 8, 1>(p, s);        // 64 x 256, one barrier / 8 ch
         return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
       case 1:
         if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);
+        else if (v == 'C') st = launch_cfg<0, 2, 2, 1, 4, 2, 8, 1>(p, s);                      // 64 x 256
         return st != 1 ? st : launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
       default:
         if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
-        else if (v == 'C') st = launch_cfg<0, 1, 1, 1, 4, 3, 16, 1>(p, s);
+        else if (v == 'C') st = launch_cfg<0, 1, 4, 1, 4, 2, 8, 1>(p, s);                      // 32 x 512
         return st != 1 ? st : launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
     }
   }
@@ -947,10 +958,11 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
   }
   if (cfg == 1) {
     if (v == 'B') st = launch_cfg<1, 2, 1, 1, 4, 2, 8, 1>(p, s);
+    else if (v == 'C') st = launch_cfg<1, 1, 2, 1, 4, 2, 8, 1>(p, s);                          // 32 x 256 positions
     return st != 1 ? st : launch_cfg<1, 2, 1, 1, 4>(p, s);
   }
   if (v == 'B') st = launch_cfg<1, 1, 1, 1, 4, 3, 8, 1>(p, s);
-  else if (v == 'C') st = launch_cfg<1, 1, 1, 1, 4, 2, 16, 1>(p, s);
+  else if (v == 'C') st = launch_cfg<1, 1, 2, 1, 4, 2, 8, 1>(p, s);
   return st != 1 ? st : launch_cfg<1, 1, 1, 1, 4, 3>(p, s);
 }
 
