@@ -150,6 +150,9 @@ struct MCParams {
   // what the MFMA + operand-fetch loop alone reaches; results are wrong), bit 1 = no barriers in the K loop (wrong too),
   // bit 2 = PIPE 1: issue all DMA pieces of the next chunk up front instead of spreading them over the MFMA stages.
   int debug;
+  // experiments only (FMGAN_MC_CLOCKPTR = device address of 2 x uint64): block 0 adds its shader-clock cycles
+  // (s_memtime) and its constant-100-MHz ticks (s_memrealtime): their ratio is the clock the chip held during the kernel
+  unsigned long long* dbg_clock;
 };
 
 constexpr int MC_KC = 8;  // input channels per LDS chunk
@@ -214,12 +217,15 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, khalf = lane >> 5;
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (p.dbg_clock) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }
 
   unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
   int si = 0;
   while (si + 1 < p.nseg && lb >= p.seg[si].block_end) ++si;
   if (si > 0) lb -= p.seg[si - 1].block_end;
-  const int thin = (MODE == 1 && p.nseg == 3) ? (si == 0 ? 1 : (si == 1 ? 2 : 0)) : 0;   // mode 1: row / column strip
+  // mode 1: taps (bit ky*3+kx) this block's segment needs — row strip: ky = 2, column strip: kx = 2, main grid: all
+  const unsigned tapmask = (MODE == 1 && p.nseg == 3) ? (si == 0 ? 0x1C0u : (si == 1 ? 0x124u : 0x1FFu)) : 0x1FFu;
   const int seg_th = p.seg[si].th, seg_nb = p.seg[si].nb, tw_log2 = p.seg[si].tw_log2;
   const int seg_m_end = p.seg[si].m_off + p.seg[si].gh, seg_n_end = p.seg[si].n_off + p.seg[si].gw;
   constexpr int SP = MODE == 2 ? 2 : 1;          // input step per position
@@ -453,23 +459,18 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     } else {
       // (tap = ky*3+kx, input-offset index j, phase = py*2+px)
       constexpr int T[9][3] = {{0, 0, 0}, {2, 1, 0}, {6, 2, 0}, {8, 3, 0}, {1, 0, 1}, {7, 2, 1}, {3, 0, 2}, {5, 1, 2}, {4, 0, 3}};
-      auto run = [&](auto keep) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q)
-          if (keep(T[q][0]))
-#pragma unroll
-            for (int m = 0; m < RM; ++m)
-#pragma unroll
-              for (int g = 0; g < RNP; ++g)
-                acc[m][g][T[q][2]] =
-                    __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[T[q][0]][m], o.b[T[q][1]][g], acc[m][g][T[q][2]], 0, 0, 0);
-      };
       // The two thin segments (last output row: positions m = h; last output column: n = w) only ever see the taps
       // whose input lies inside the image — ky = 2 resp. kx = 2: every other product has a zero operand.  Their
-      // blocks issue 3 of the 9 MFMAs per channel pair (same sums, bit for bit) and finish three times sooner.
-      if (thin == 0) run([](int) { return true; });
-      else if (thin == 1) run([](int tap) { return tap / 3 == 2; });
-      else run([](int tap) { return tap % 3 == 2; });
+      // blocks skip those MFMAs (a wave-uniform bit per tap: same sums, bit for bit) and finish three times sooner.
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (tapmask & (1u << T[q][0]))
+#pragma unroll
+          for (int m = 0; m < RM; ++m)
+#pragma unroll
+            for (int g = 0; g < RNP; ++g)
+              acc[m][g][T[q][2]] =
+                  __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[T[q][0]][m], o.b[T[q][1]][g], acc[m][g][T[q][2]], 0, 0, 0);
     }
   };
 
@@ -732,6 +733,10 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
         }
       }
     }
+  }
+  if (p.dbg_clock && tid == 0 && (blockIdx.x & 63) == 0) {
+    atomicAdd(p.dbg_clock, __builtin_readcyclecounter() - clk0);
+    atomicAdd(p.dbg_clock + 1, wall_clock64() - rt0);
   }
   if constexpr (RGB) {
     // second pass over the activated values (now in the accumulators): rgb = sum over rows of act * wmod, where
@@ -1356,6 +1361,9 @@ int modconv2d_impl(const float* in, const float* wt, const float* style, const f
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("FMGAN_MC_DEBUG"); dbg = e ? atoi(e) : 0; }
     p.debug = dbg;
+    static long long clk = -1;
+    if (clk < 0) { const char* e = getenv("FMGAN_MC_CLOCKPTR"); clk = e ? atoll(e) : 0; }
+    p.dbg_clock = (unsigned long long*)clk;
   }
   if (rgb) {
     p.rgb_wmod = rgb->wmod; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip; p.rgb_out = rgb->out; p.rgb_c = rgb->c;

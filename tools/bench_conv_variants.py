@@ -22,6 +22,12 @@ def worker(batch):
     from op import _native
     d = torch.device('cuda', 0)
     out = []
+    clk = torch.zeros(2, dtype=torch.int64, device=d)
+    use_clk = os.environ.get('FMGAN_MC_CLOCKPTR') == str(clk.data_ptr())
+    if os.environ.get('FMGAN_MC_CLOCK') == '1' and not use_clk:
+        # the library reads the address once at its first launch: hand it over through the environment before that
+        os.environ['FMGAN_MC_CLOCKPTR'] = str(clk.data_ptr())
+        use_clk = True
     for (r, cin, cout, mode) in LAYERS:
         g = torch.Generator(device=d).manual_seed(r * 7 + mode)
         x = torch.randn(batch, cin, r, r, device=d, generator=g)
@@ -40,7 +46,14 @@ def worker(batch):
             a.record(); _native.modconv2d(x, wt, s, dm, mode); b.record(); b.synchronize()
             ts.append(a.elapsed_time(b))
         ts.sort()
-        out.append(dict(res=r, cin=cin, cout=cout, mode=mode, us=ts[len(ts) // 2] * 1e3, digest=digest))
+        ghz = None
+        if use_clk:
+            clk.zero_()
+            _native.modconv2d(x, wt, s, dm, mode)
+            torch.cuda.synchronize()
+            c = clk.cpu().tolist()
+            ghz = c[0] / max(1, c[1]) * 0.1          # s_memrealtime ticks at 100 MHz
+        out.append(dict(res=r, cin=cin, cout=cout, mode=mode, us=ts[len(ts) // 2] * 1e3, digest=digest, ghz=ghz))
         del x, y
     print('RESULT ' + json.dumps(out))
 
@@ -86,8 +99,9 @@ def table(batch):
             tot[v] += us[v]
         best_tot += us[bv]
         flops_tot += fl
+        ghz = res[bv][i].get('ghz')
         print(f"| {r}^2 {cin}->{cout} | {mode} | " + ' | '.join(f"{us.get(v, float('nan')):.1f}" for v in 'ABC') +
-              f" | {bv} | {fl / us[bv] / 1e6:.1f} | {'yes' if same else 'NO'} |")
+              f" | {bv} | {fl / us[bv] / 1e6:.1f} | {'yes' if same else 'NO'} |" + (f' clock {ghz:.2f} GHz' if ghz else ''))
     print(f"| total | | " + ' | '.join(f"{tot.get(v, float('nan')):.0f}" for v in 'ABC') + f" | {best_tot:.0f} | {flops_tot / best_tot / 1e6:.1f} | |")
 
 

@@ -9,8 +9,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int RM, int RNP, int TAPS, int WIDE, int MINB>
-__global__ __launch_bounds__(256, MINB) void P(float* out, int iters) {
+__global__ __launch_bounds__(256, MINB) void P(float* out, int iters, unsigned long long* clk = nullptr) {
   extern __shared__ float smem[];
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
   for (int i = threadIdx.x; i < 8192; i += 256) smem[i] = 1e-3f * (i & 255);
   __syncthreads();
   const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
@@ -62,6 +63,10 @@ __global__ __launch_bounds__(256, MINB) void P(float* out, int iters) {
   float s = 0.f;
   for (int m = 0; m < RM; ++m) for (int g = 0; g < RNP; ++g) for (int r = 0; r < 16; ++r) s += acc[m][g][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (clk && threadIdx.x == 0 && (blockIdx.x & 63) == 0) {
+    atomicAdd(clk, __builtin_readcyclecounter() - c0);
+    atomicAdd(clk + 1, wall_clock64() - r0);
+  }
 }
 
 template <typename K>
@@ -69,16 +74,20 @@ void run(const char* name, K kern, int mfma_per_stage, float* out) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int bpc = 1; bpc <= 3; ++bpc) {
     const int blocks = 256 * bpc, iters = 400;
-    kern<<<blocks, 256, 8192 * 4>>>(out, 10);
+    kern<<<blocks, 256, 8192 * 4>>>(out, 10, nullptr);
     hipDeviceSynchronize();
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
-      hipEventRecord(e0); kern<<<blocks, 256, 8192 * 4>>>(out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventRecord(e0); kern<<<blocks, 256, 8192 * 4>>>(out, iters, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) best = ms;
     }
     double flop = (double)blocks * 4 * iters * 12.0 * mfma_per_stage * 4096.0;
-    printf("%-34s blocks/CU %d: %7.2f ms  %6.1f TFLOP/s\n", name, bpc, best, flop / best / 1e9);
+    unsigned long long* clk; hipMalloc(&clk, 16); hipMemset(clk, 0, 16);
+    kern<<<blocks, 256, 8192 * 4>>>(out, iters, clk);
+    unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost); hipFree(clk);
+    printf("%-34s blocks/CU %d: %7.2f ms  %6.1f TFLOP/s  shader clock %.2f GHz\n", name, bpc, best, flop / best / 1e9,
+           (double)h[0] / (double)(h[1] ? h[1] : 1) * 0.1);
   }
 }
 
@@ -93,3 +102,4 @@ int main() {
   run("wide          RM2 RNP4 T3 b32", P<2, 4, 3, 0, 2>, 24, out);
   return 0;
 }
+// (clock check: run with argument "clock" to print the shader clock held during the 128x128-like loop)
