@@ -942,11 +942,11 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
     switch (cfg) {
       case 0:
         if (v == 'B') st = launch_cfg<0, 2, 2, 2, 2, 3, 4, 1>(p, s);
-        else if (v == 'C' && !p.rgb_out) st = launch_cfg<0, 2, 2, 1, 4, 2, 8, 1>(p, s);        // 64 x 256, one barrier / 8 ch
+        else if (v == 'C' && !p.rgb_out) st = launch_cfg<0, 4, 2, 1, 4, 2, 4, 1>(p, s);        // 128 x 256: 0.75 reads / MFMA
         return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
       case 1:
         if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);
-        else if (v == 'C') st = launch_cfg<0, 2, 2, 1, 4, 2, 8, 1>(p, s);                      // 64 x 256
+        else if (v == 'C' && !p.rgb_out) st = launch_cfg<0, 2, 4, 1, 4, 2, 8, 1>(p, s);        // 64 x 512
         return st != 1 ? st : launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
       default:
         if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
