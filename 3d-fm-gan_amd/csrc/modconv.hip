@@ -893,7 +893,9 @@ inline char mc_variant(int mode, int cfg) {
   static char table[3][3];
   static bool init = false;
   if (!init) {
-    const char defaults[3][3] = {{'A', 'A', 'A'}, {'A', 'A', 'A'}, {'A', 'A', 'A'}};
+    // measured on MI355X (profiles/r02_modconv_variants.md): plain conv, Cout >= 96: 128 x 256 tile by LDS-DMA (C);
+    // Cout >= 48: 64 x 256 (C); Cout < 48: register pipeline; transposed conv, Cout >= 48: LDS-DMA (B)
+    const char defaults[3][3] = {{'C', 'C', 'A'}, {'A', 'B', 'A'}, {'A', 'A', 'A'}};
     for (int m = 0; m < 3; ++m)
       for (int c = 0; c < 3; ++c) {
         char name[32];
@@ -935,18 +937,33 @@ inline int cfg_blocks_per_cu(int mode, int cfg) {
   return cfg == 0 ? 2 : (cfg == 1 ? (mode == 0 ? 3 : 2) : 4);
 }
 
+// blocks a (BM x BN) tiling of this launch would have (all segments)
+inline long long blocks_with(const MCParams& p, int BM, int BN) {
+  long long blocks = 0;
+  for (int i = 0; i < p.nseg; ++i) {
+    MCParams::Seg sg = p.seg[i];
+    blocks += plan_segment(sg, p.batch, BN);
+  }
+  return blocks * ((p.cout + BM - 1) / BM);
+}
+
 inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
-  const char v = mc_variant(mode, cfg);
+  char v = mc_variant(mode, cfg);
+  // the large-tile variants need enough tiles to fill the chip twice over (2 blocks per CU); smaller launches keep
+  // the 128-position tiles (and their split-K plan)
+  if (mode == 0 && v == 'C' && cfg < 2 &&
+      (p.ksplit > 1 || blocks_with(p, cfg == 0 ? 128 : 64, 256) < 2LL * FMGAN_NUM_CU || p.rgb_out))
+    v = 'A';
   int st = 1;
   if (mode == 0) {
     switch (cfg) {
       case 0:
         if (v == 'B') st = launch_cfg<0, 2, 2, 2, 2, 3, 4, 1>(p, s);
-        else if (v == 'C' && !p.rgb_out) st = launch_cfg<0, 4, 2, 1, 4, 2, 4, 1>(p, s);        // 128 x 256: 0.75 reads / MFMA
+        else if (v == 'C') st = launch_cfg<0, 4, 2, 1, 4, 2, 4, 1>(p, s);                      // 128 x 256: 0.75 reads / MFMA
         return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
       case 1:
         if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);
-        else if (v == 'C' && !p.rgb_out) st = launch_cfg<0, 2, 4, 1, 4, 2, 8, 1>(p, s);        // 64 x 512
+        else if (v == 'C') st = launch_cfg<0, 2, 2, 1, 4, 2, 8, 1>(p, s);                      // 64 x 256
         return st != 1 ? st : launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
       default:
         if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
