@@ -361,6 +361,12 @@ struct U2Params {
   int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw, bw, bh;   // bw/bh: 4x2 blocks per row/col
 };
 
+// A thread owns a 2 x 4 output block whose origin is even in both directions, so which taps meet a non-zero sample of
+// the zero-stuffed input depends only on the PARITY of the padding (template parameters): every tap and input index
+// below is a compile-time constant.  The 2 x 4 outputs read a 3 x 4 input neighbourhood (one 16-byte load per row when
+// it lies inside the image) and cost 32 FMAs — the first version re-derived the taps per output with 16-way selects
+// and issued 32 scalar loads (61 us for [24,512,512] -> [24,1024,1024]; store-bound at ~25 us).
+template <int PY, int PX>
 __global__ __launch_bounds__(256) void ufd_up2_f32(const float* __restrict__ in, const float* __restrict__ kern,
                                                    float* __restrict__ out, const U2Params p) {
   float kf[4][4];
@@ -369,6 +375,17 @@ __global__ __launch_bounds__(256) void ufd_up2_f32(const float* __restrict__ in,
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx)
       kf[ky][kx] = (ky < p.kh && kx < p.kw) ? kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
+  // output (dy, dx) of a block takes taps ky = KY0(dy) + 2a, kx = KX0(dx) + 2c from input (RY(dy,a), CX(dx,c)) relative
+  // to (oy0/2 - pad_y0/2, ox0/2 - pad_x0/2); >> is an arithmetic shift (floor), as the zero-stuffed index needs
+  constexpr auto KY0 = [](int dy) { return (PY - dy) & 1; };
+  constexpr auto KX0 = [](int dx) { return (PX - dx) & 1; };
+  constexpr auto RY = [](int dy, int a) { return (dy + ((PY - dy) & 1) + 2 * a - PY) >> 1; };
+  constexpr auto CX = [](int dx, int c) { return (dx + ((PX - dx) & 1) + 2 * c - PX) >> 1; };
+  constexpr int RMIN = RY(0, 0) < RY(1, 0) ? RY(0, 0) : RY(1, 0);
+  constexpr int CMIN = CX(0, 0) < CX(1, 0) ? CX(0, 0) : CX(1, 0);
+  static_assert(RY(1, 1) - RMIN <= 2 && RY(0, 1) - RMIN <= 2, "3 input rows");
+  static_assert(CX(3, 1) - CMIN <= 3 && CX(2, 1) - CMIN <= 3, "4 input columns");
+  const int qy = (p.pad_y0 - PY) / 2, qx = (p.pad_x0 - PX) / 2;      // exact: pad - parity is even (also when negative)
   const long long total = (long long)p.planes * p.bh * p.bw;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int bx = (int)(idx % p.bw);
@@ -378,43 +395,38 @@ __global__ __launch_bounds__(256) void ufd_up2_f32(const float* __restrict__ in,
     const float* pin = in + pl * (long long)p.in_h * p.in_w;
     float* pout = out + pl * (long long)p.out_h * p.out_w;
     const int ox0 = bx * 4, oy0 = by * 2;
+    const int iy0 = by - qy + RMIN, ix0 = bx * 2 - qx + CMIN;          // first row / column of the neighbourhood
+    float v[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = iy0 + r;
+      const bool yok = iy >= 0 && iy < p.in_h;
+      const float* rp = pin + (long long)(yok ? iy : 0) * p.in_w;
+      if (yok && ix0 >= 0 && ix0 + 3 < p.in_w) {
+        const f32x4_u q = *reinterpret_cast<const f32x4_u*>(rp + ix0);
+        v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[r][c] = (yok && ix0 + c >= 0 && ix0 + c < p.in_w) ? rp[ix0 + c] : 0.f;
+      }
+    }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
       const int oy = oy0 + dy;
       if (oy >= p.out_h) break;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const int ky0 = (p.pad_y0 - oy) & 1;          // taps with (oy + ky - pad_y0) even
+      // same order of accumulation as the one-output-at-a-time form: ky outer, kx inner
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int ky = ky0 + 2 * a;
-        const int uy = oy + ky - p.pad_y0;           // even by construction; arithmetic shift = floor for negatives
-        const int iy = uy >> 1;
-        const bool yok = uy >= 0 && iy < p.in_h;
-        const float* rp = pin + (long long)iy * p.in_w;
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-          const int ox = ox0 + dx;
-          const int kx0 = (p.pad_x0 - ox) & 1;
+        for (int dx = 0; dx < 4; ++dx)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const int kx = kx0 + 2 * c;
-            const int ux = ox + kx - p.pad_x0;
-            const int ix = ux >> 1;
-            const float x = (yok && ux >= 0 && ix < p.in_w) ? rp[ix] : 0.f;
-            // kf[ky][kx] with runtime (ky,kx) in {0..3}: select from registers
-            float w = 0.f;
-#pragma unroll
-            for (int yy = 0; yy < 4; ++yy)
-#pragma unroll
-              for (int xx = 0; xx < 4; ++xx) w = (yy == ky && xx == kx) ? kf[yy][xx] : w;
-            acc[dx] = fmaf(x, w, acc[dx]);
-          }
-        }
-      }
+          for (int c = 0; c < 2; ++c)
+            acc[dx] = fmaf(v[RY(dy, a) - RMIN][CX(dx, c) - CMIN], kf[KY0(dy) + 2 * a][KX0(dx) + 2 * c], acc[dx]);
       float* op = pout + (long long)oy * p.out_w + ox0;
       if (ox0 + 4 <= p.out_w) {
-        f32x4_u t; t.x = acc[0]; t.y = acc[1]; t.z = acc[2]; t.w = acc[3];
-        *reinterpret_cast<f32x4_u*>(op) = t;
+        f32x4_u q; q.x = acc[0]; q.y = acc[1]; q.z = acc[2]; q.w = acc[3];
+        *reinterpret_cast<f32x4_u*>(op) = q;
       } else {
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx)
@@ -514,8 +526,14 @@ int launch_up2(const void* in, const void* kern, void* out, const UfdParams& p, 
   long long blocks = (total + 255) / 256;
   const long long cap = (long long)FMGAN_NUM_CU * 32;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(ufd_up2_f32, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in, (const float*)kern,
-                     (float*)out, t);
+  const int par = (p.pad_y0 & 1) * 2 + (p.pad_x0 & 1);
+  const dim3 g((unsigned)blocks), b(256);
+  switch (par) {
+    case 0: hipLaunchKernelGGL((ufd_up2_f32<0, 0>), g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, t); break;
+    case 1: hipLaunchKernelGGL((ufd_up2_f32<0, 1>), g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, t); break;
+    case 2: hipLaunchKernelGGL((ufd_up2_f32<1, 0>), g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, t); break;
+    default: hipLaunchKernelGGL((ufd_up2_f32<1, 1>), g, b, 0, s, (const float*)in, (const float*)kern, (float*)out, t); break;
+  }
   return fmgan_check_launch();
 }
 
