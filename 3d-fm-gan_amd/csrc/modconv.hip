@@ -1157,6 +1157,129 @@ __global__ __launch_bounds__(256) void modconv_wgrad_finish_f32(const float* __r
   }
 }
 
+
+// ---- 64 x 64 weight-gradient tile (round 2).  The 32 x 32 kernel above spends most of its time filling LDS: every
+// 144 MFMAs of a wave need a new 128-pixel tile, and a block re-reads gz / u for a quarter of the output a 64 x 64 tile
+// covers.  Here a block owns 64 (o) x 64 (i), its four waves the four 32 x 32 quadrants, and ALL of them walk the same
+// 2 x TW pixels per step: 2 TW/2... = TW K-steps x 9 MFMAs = 288 MFMAs per wave between two barriers (TW = 32), with the
+// pixel pair of an MFMA (its K = 2) taken from the two rows — so consecutive K-steps move one pixel along x and the
+// 3 x 3 window of the shifted operand slides: 3 new LDS reads per step instead of 9 (+1 for gz): 4 reads per 9 MFMAs.
+struct WG64Params {
+  const float* go; const float* d; const float* x; const float* s; float* partial;
+  int batch, cin, cout, h, w;
+  int tiles_x, tiles_y, ntiles, ksplit, tiles_per_split, o_tiles, i_tiles;
+};
+
+template <int TWL2>
+__global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p) {
+  constexpr int TW = 1 << TWL2, PA = 2 * TW + 1, PWP = TW + 2, PB = 4 * PWP + 1;   // odd pitches: conflict-free over channels
+  extern __shared__ float smem[];
+  float* Gz = smem;               // [64][PA]   d * go, rows y0, y0+1
+  float* Us = smem + 64 * PA;     // [64][PB]   s * x,  rows y0-1 .. y0+2, columns x0-1 .. x0+TW
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int oq = wave >> 1, iq = wave & 1;
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int o_tile = lb % p.o_tiles;
+  const int i_tile = (lb / p.o_tiles) % p.i_tiles;
+  const int ks = lb / (p.o_tiles * p.i_tiles);
+  const int o0 = o_tile * 64, i0 = i_tile * 64;
+  const long long hw = (long long)p.h * p.w;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* ga = Gz + (oq * 32 + l31) * PA + khalf * TW;
+  const float* ub = Us + (iq * 32 + l31) * PB + khalf * PWP;
+  const int t_begin = ks * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % p.tiles_x;
+    const int ty = (tile / p.tiles_x) % p.tiles_y;
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * 2, x0 = tx * TW;
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 2 * TW; idx += 256) {
+      const int o = idx / (2 * TW), rc = idx - o * 2 * TW;
+      const int y = y0 + (rc >> TWL2), x = x0 + (rc & (TW - 1));
+      float v = 0.f;
+      if (o0 + o < p.cout && y < p.h && x < p.w) {
+        const long long ch = (long long)b * p.cout + o0 + o;
+        v = p.go[ch * hw + (long long)y * p.w + x];
+        if (p.d) v *= p.d[ch];
+      }
+      Gz[o * PA + rc] = v;
+    }
+    for (int idx = tid; idx < 64 * 4 * PWP; idx += 256) {
+      const int i = idx / (4 * PWP), q = idx - i * 4 * PWP;
+      const int y = y0 - 1 + q / PWP, x = x0 - 1 + q % PWP;
+      float v = 0.f;
+      if (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w) {
+        const long long ch = (long long)b * p.cin + i0 + i;
+        v = p.x[ch * hw + (long long)y * p.w + x] * p.s[ch];
+      }
+      Us[i * PB + q] = v;
+    }
+    __syncthreads();
+    // K-step j: pixels (y0 + khalf, x0 + j); tap (ky, kx) reads patch row khalf + ky, column j + kx.
+    float win[3][3];                       // win[ky][c % 3] = column c of patch row khalf + ky
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) { win[ky][0] = ub[ky * PWP + 0]; win[ky][1] = ub[ky * PWP + 1]; }
+    float a_cur = ga[0], a_nxt = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) win[ky][2] = ub[ky * PWP + 2];
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      float nw[3] = {0.f, 0.f, 0.f};
+      if (j + 1 < TW) {                    // operands of step j + 1 while step j is on the matrix pipe
+        a_nxt = ga[j + 1];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) nw[ky] = ub[ky * PWP + j + 3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, win[ky][(j + kx) % 3], acc[ky * 3 + kx], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) win[ky][j % 3] = nw[ky];     // column j leaves the window, column j + 3 enters
+    }
+  }
+  float* slab = p.partial + (long long)ks * 9 * p.cout * p.cin;
+  const int i = i0 + iq * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + oq * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (o < p.cout && i < p.cin) slab[((long long)t * p.cout + o) * p.cin + i] = acc[t][r];
+    }
+}
+
+inline bool wgrad64_ok(int cin, int cout, int w) { return cin >= 48 && cout >= 48 && w >= 16; }
+
+inline void wgrad64_plan(WG64Params& p) {
+  const int TW = p.w >= 32 ? 32 : 16;
+  p.tiles_x = (p.w + TW - 1) / TW;
+  p.tiles_y = (p.h + 1) / 2;
+  p.ntiles = p.batch * p.tiles_x * p.tiles_y;
+  p.o_tiles = (p.cout + 63) / 64;
+  p.i_tiles = (p.cin + 63) / 64;
+  const int pairs = p.o_tiles * p.i_tiles;
+  int ks = (FMGAN_NUM_CU * 4 + pairs - 1) / pairs;      // ~2 rounds of 2 blocks per CU
+  const int max_ks = p.ntiles / 4 > 0 ? p.ntiles / 4 : 1; // at least 4 tile steps per block
+  if (ks > max_ks) ks = max_ks;
+  if (ks < 1) ks = 1;
+  p.tiles_per_split = (p.ntiles + ks - 1) / ks;
+  p.ksplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+}
+
 inline void wgrad_plan(WGParams& p) {
   p.tw_log2 = p.w >= 32 ? 5 : 4;
   const int TW = 1 << p.tw_log2;
@@ -1474,6 +1597,12 @@ extern "C" int fmgan_modconv2d_rgb_f32(const float* in, const float* wt, const f
 
 extern "C" long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w < 16) return 0;
+  if (wgrad64_ok(cin, cout, w)) {
+    WG64Params q{};
+    q.batch = batch; q.cin = cin; q.cout = cout; q.h = h; q.w = w;
+    wgrad64_plan(q);
+    return (long long)q.ksplit * 9 * cout * cin * (long long)sizeof(float);
+  }
   WGParams p{};
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
   wgrad_plan(p);
@@ -1488,6 +1617,32 @@ extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, cons
   if (!go || !x || !style || !gw || !workspace) return FMGAN_EINVAL;
   if ((long long)batch * (cin > cout ? cin : cout) * h * w >= (1LL << 40)) return FMGAN_EOVERFLOW;
   if ((long long)h * w >= (1LL << 31) || cin > (1 << 20) || cout > (1 << 20)) return FMGAN_EOVERFLOW;
+  if (wgrad64_ok(cin, cout, w)) {
+    WG64Params q{};
+    q.go = go; q.d = demod; q.x = x; q.s = style; q.partial = (float*)workspace;
+    q.batch = batch; q.cin = cin; q.cout = cout; q.h = h; q.w = w;
+    wgrad64_plan(q);
+    if (workspace_bytes < (long long)q.ksplit * 9 * cout * cin * (long long)sizeof(float)) return FMGAN_EINVAL;
+    const long long nblk = (long long)q.o_tiles * q.i_tiles * q.ksplit;
+    if (nblk > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (w >= 32) {
+      constexpr int TW = 32;
+      const size_t lds = sizeof(float) * 64 * ((2 * TW + 1) + (4 * (TW + 2) + 1));
+      hipLaunchKernelGGL((modconv_wgrad64_f32<5>), dim3((unsigned)nblk), dim3(256), lds, st_, q);
+    } else {
+      constexpr int TW = 16;
+      const size_t lds = sizeof(float) * 64 * ((2 * TW + 1) + (4 * (TW + 2) + 1));
+      hipLaunchKernelGGL((modconv_wgrad64_f32<4>), dim3((unsigned)nblk), dim3(256), lds, st_, q);
+    }
+    int st2 = fmgan_check_launch();
+    if (st2 != FMGAN_OK) return st2;
+    int fb2 = (cout * cin * 9 + 255) / 256;
+    if (fb2 > FMGAN_NUM_CU * 16) fb2 = FMGAN_NUM_CU * 16;
+    hipLaunchKernelGGL(modconv_wgrad_finish_f32, dim3(fb2), dim3(256), 0, st_, (const float*)workspace, gw, cout, cin,
+                       q.ksplit, scale);
+    return fmgan_check_launch();
+  }
   WGParams p{};
   p.go = go; p.d = demod; p.x = x; p.s = style; p.partial = (float*)workspace;
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
