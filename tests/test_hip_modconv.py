@@ -253,7 +253,11 @@ def test_first_order_backward_on_hip_vs_oracle(cfg):
                                    err_msg=name)
 
 
-@pytest.mark.parametrize('shape', [(2, 64, 96, 64, 64), (1, 32, 32, 128, 128), (3, 100, 50, 17, 33), (8, 512, 512, 16, 16)])
+@pytest.mark.parametrize('shape', [
+    # (b, cin, cout, h, w): 32 x 32-tile kernel (< 48 channels) and 64 x 64-tile kernel (TW = 32 / 16, ragged sizes,
+    # partial channel tiles, odd heights, widths that are no multiple of the tile)
+    (2, 64, 96, 64, 64), (1, 32, 32, 128, 128), (3, 100, 50, 17, 33), (8, 512, 512, 16, 16), (2, 64, 64, 64, 64),
+    (1, 128, 64, 40, 48), (4, 70, 130, 33, 20), (1, 48, 200, 9, 16), (2, 256, 256, 128, 128)])
 def test_wgrad_kernel_vs_fp64(shape):
     """fmgan_modconv_wgrad_f32 vs a float64 conv weight gradient of the same (d*go, s*x) on the GPU."""
     from op import _native
