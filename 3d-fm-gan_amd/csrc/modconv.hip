@@ -1173,9 +1173,10 @@ struct WG64Params {
 template <int TWL2>
 __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p) {
   constexpr int TW = 1 << TWL2, PA = 2 * TW + 1, PWP = TW + 2, PB = 4 * PWP + 1;   // odd pitches: conflict-free over channels
+  constexpr int NA4 = TW / 8, NB4 = TW / 4, NH = 2;      // per thread: float4 of gz, float4 of u, halo scalars of u
   extern __shared__ float smem[];
-  float* Gz = smem;               // [64][PA]   d * go, rows y0, y0+1
-  float* Us = smem + 64 * PA;     // [64][PB]   s * x,  rows y0-1 .. y0+2, columns x0-1 .. x0+TW
+  float* Gz = smem;               // [64][PA]   go, rows y0, y0+1                      (d applied at the operand fetch)
+  float* Us = smem + 64 * PA;     // [64][PB]   x,  rows y0-1 .. y0+2, columns x0-1 .. x0+TW   (s applied at the fetch)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int oq = wave >> 1, iq = wave & 1;
@@ -1185,6 +1186,8 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p
   const int ks = lb / (p.o_tiles * p.i_tiles);
   const int o0 = o_tile * 64, i0 = i_tile * 64;
   const long long hw = (long long)p.h * p.w;
+  // rows of both tensors start 16-byte aligned and tiles never straddle the right edge inside a float4
+  const bool vec = (p.w & 3) == 0 && ((((uintptr_t)p.go) | ((uintptr_t)p.x)) & 15) == 0;
 
   f32x16 acc[9];
 #pragma unroll
@@ -1192,44 +1195,114 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const float* ga = Gz + (oq * 32 + l31) * PA + khalf * TW;
-  const float* ub = Us + (iq * 32 + l31) * PB + khalf * PWP;
-  const int t_begin = ks * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // ---- staging plan: everything a tile step needs is loaded into registers while the previous step is on the
+  // matrix pipe and written to LDS after the barrier (the forward kernel's register pipeline)
+  f32x4 a4[NA4], b4[NB4];
+  float bh[NH], d_n = 1.f, s_n = 1.f, d_lane = 1.f, s_lane = 1.f;
+  const int my_o = o0 + oq * 32 + l31, my_i = i0 + iq * 32 + l31;
+  auto decode = [&](int tile, int& b, int& y0, int& x0) {
     const int tx = tile % p.tiles_x;
     const int ty = (tile / p.tiles_x) % p.tiles_y;
-    const int b = tile / (p.tiles_x * p.tiles_y);
-    const int y0 = ty * 2, x0 = tx * TW;
-    __syncthreads();
+    b = tile / (p.tiles_x * p.tiles_y);
+    y0 = ty * 2; x0 = tx * TW;
+  };
+  auto issue = [&](int tile) {
+    int b, y0, x0;
+    decode(tile, b, y0, x0);
+    d_n = (p.d && my_o < p.cout) ? p.d[(long long)b * p.cout + my_o] : 1.f;
+    s_n = my_i < p.cin ? p.s[(long long)b * p.cin + my_i] : 0.f;
+    if (!vec) return;
+#pragma unroll
+    for (int k = 0; k < NA4; ++k) {
+      const int q = tid + 256 * k;
+      const int o = q / (2 * TW / 4), rem = q % (2 * TW / 4);
+      const int y = y0 + rem / (TW / 4), x = x0 + 4 * (rem % (TW / 4));
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o0 + o < p.cout && y < p.h && x < p.w)
+        v = *reinterpret_cast<const f32x4*>(p.go + ((long long)b * p.cout + o0 + o) * hw + (long long)y * p.w + x);
+      a4[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NB4; ++k) {
+      const int q = tid + 256 * k;
+      const int i = q / TW, rem = q % TW;                 // 4 rows x TW/4 float4 per channel
+      const int y = y0 - 1 + rem / (TW / 4), x = x0 + 4 * (rem % (TW / 4));
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i0 + i < p.cin && y >= 0 && y < p.h && x < p.w)
+        v = *reinterpret_cast<const f32x4*>(p.x + ((long long)b * p.cin + i0 + i) * hw + (long long)y * p.w + x);
+      b4[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const int q = tid + 256 * k;
+      const int i = q >> 3, r = (q >> 1) & 3, side = q & 1;
+      const int y = y0 - 1 + r, x = side ? x0 + TW : x0 - 1;
+      bh[k] = (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w)
+                  ? p.x[((long long)b * p.cin + i0 + i) * hw + (long long)y * p.w + x] : 0.f;
+    }
+  };
+  auto commit = [&](int tile) {
+    d_lane = d_n; s_lane = s_n;
+    if (vec) {
+#pragma unroll
+      for (int k = 0; k < NA4; ++k) {
+        const int q = tid + 256 * k;
+        const int o = q / (2 * TW / 4), rem = q % (2 * TW / 4);
+        float* dst = Gz + o * PA + 4 * rem;                // (row r, column 4*c4) = r*TW + 4*c4 = 4*rem
+        dst[0] = a4[k].x; dst[1] = a4[k].y; dst[2] = a4[k].z; dst[3] = a4[k].w;
+      }
+#pragma unroll
+      for (int k = 0; k < NB4; ++k) {
+        const int q = tid + 256 * k;
+        const int i = q / TW, rem = q % TW;
+        float* dst = Us + i * PB + (rem / (TW / 4)) * PWP + 1 + 4 * (rem % (TW / 4));
+        dst[0] = b4[k].x; dst[1] = b4[k].y; dst[2] = b4[k].z; dst[3] = b4[k].w;
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const int q = tid + 256 * k;
+        const int i = q >> 3, r = (q >> 1) & 3, side = q & 1;
+        Us[i * PB + r * PWP + (side ? TW + 1 : 0)] = bh[k];
+      }
+      return;
+    }
+    // widths that are no multiple of 4 / unaligned tensors: guarded scalar fill, not prefetched
+    int b, y0, x0;
+    decode(tile, b, y0, x0);
     for (int idx = tid; idx < 64 * 2 * TW; idx += 256) {
       const int o = idx / (2 * TW), rc = idx - o * 2 * TW;
       const int y = y0 + (rc >> TWL2), x = x0 + (rc & (TW - 1));
       float v = 0.f;
-      if (o0 + o < p.cout && y < p.h && x < p.w) {
-        const long long ch = (long long)b * p.cout + o0 + o;
-        v = p.go[ch * hw + (long long)y * p.w + x];
-        if (p.d) v *= p.d[ch];
-      }
+      if (o0 + o < p.cout && y < p.h && x < p.w) v = p.go[((long long)b * p.cout + o0 + o) * hw + (long long)y * p.w + x];
       Gz[o * PA + rc] = v;
     }
     for (int idx = tid; idx < 64 * 4 * PWP; idx += 256) {
       const int i = idx / (4 * PWP), q = idx - i * 4 * PWP;
       const int y = y0 - 1 + q / PWP, x = x0 - 1 + q % PWP;
       float v = 0.f;
-      if (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w) {
-        const long long ch = (long long)b * p.cin + i0 + i;
-        v = p.x[ch * hw + (long long)y * p.w + x] * p.s[ch];
-      }
+      if (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w)
+        v = p.x[((long long)b * p.cin + i0 + i) * hw + (long long)y * p.w + x];
       Us[i * PB + q] = v;
     }
+  };
+
+  const float* ga = Gz + (oq * 32 + l31) * PA + khalf * TW;
+  const float* ub = Us + (iq * 32 + l31) * PB + khalf * PWP;
+  const int t_begin = ks * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
+  if (t_begin < t_end) issue(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                       // every wave is done reading the previous step
+    commit(tile);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 1 < t_end) issue(tile + 1);  // in flight during this step's MFMAs
     // K-step j: pixels (y0 + khalf, x0 + j); tap (ky, kx) reads patch row khalf + ky, column j + kx.
-    float win[3][3];                       // win[ky][c % 3] = column c of patch row khalf + ky
+    float win[3][3];                       // win[ky][c % 3] = s * column c of patch row khalf + ky
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) { win[ky][0] = ub[ky * PWP + 0]; win[ky][1] = ub[ky * PWP + 1]; }
-    float a_cur = ga[0], a_nxt = 0.f;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) win[ky][2] = ub[ky * PWP + 2];
+      for (int c = 0; c < 3; ++c) win[ky][c] = ub[ky * PWP + c] * s_lane;
+    float a_cur = ga[0] * d_lane, a_nxt = 0.f;
 #pragma unroll
     for (int j = 0; j < TW; ++j) {
       __builtin_amdgcn_sched_barrier(0);
@@ -1246,19 +1319,18 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p
         for (int kx = 0; kx < 3; ++kx)
           acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, win[ky][(j + kx) % 3], acc[ky * 3 + kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      a_cur = a_nxt;
+      a_cur = a_nxt * d_lane;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) win[ky][j % 3] = nw[ky];     // column j leaves the window, column j + 3 enters
+      for (int ky = 0; ky < 3; ++ky) win[ky][j % 3] = nw[ky] * s_lane;   // column j leaves the window, column j + 3 enters
     }
   }
   float* slab = p.partial + (long long)ks * 9 * p.cout * p.cin;
-  const int i = i0 + iq * 32 + l31;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = o0 + oq * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      if (o < p.cout && i < p.cin) slab[((long long)t * p.cout + o) * p.cin + i] = acc[t][r];
+      if (o < p.cout && my_i < p.cin) slab[((long long)t * p.cout + o) * p.cin + my_i] = acc[t][r];
     }
 }
 
