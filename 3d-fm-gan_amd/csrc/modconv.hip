@@ -1165,29 +1165,40 @@ __global__ __launch_bounds__(256) void modconv_wgrad_finish_f32(const float* __r
 // pixel pair of an MFMA (its K = 2) taken from the two rows — so consecutive K-steps move one pixel along x and the
 // 3 x 3 window of the shifted operand slides: 3 new LDS reads per step instead of 9 (+1 for gz): 4 reads per 9 MFMAs.
 struct WG64Params {
-  const float* go; const float* d; const float* x; const float* s; float* partial;
-  int batch, cin, cout, h, w;
-  int tiles_x, tiles_y, ntiles, ksplit, tiles_per_split, o_tiles, i_tiles;
+  // R[t][a][b] = sum_{n,y,x} (sa[n,a] * A[n,a,y,x]) * (sb[n,b] * B[n,b, SP*y + ky - ORG, SP*x + kx - ORG])
+  //   SP = 1, ORG = 1: plain conv        A = go [cout, h, w],          B = x  [cin, h, w]         gw[o=a][i=b]
+  //   SP = 2, ORG = 0: transposed conv   A = x  [cin, h, w],           B = go [cout, 2h+1, 2w+1]  gw[o=b][i=a]
+  //   SP = 2, ORG = 0: stride-2 conv     A = go [cout, h', w'],        B = x  [cin, h, w]         gw[o=a][i=b]
+  const float* A; const float* sa; const float* B; const float* sb; float* partial;
+  int batch, ca, cb, ha, wa, hb, wb;
+  int tiles_x, tiles_y, ntiles, ksplit, tiles_per_split, a_tiles, b_tiles;
 };
 
-template <int TWL2>
+template <int TWL2, int SP>
 __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p) {
-  constexpr int TW = 1 << TWL2, PA = 2 * TW + 1, PWP = TW + 2, PB = 4 * PWP + 1;   // odd pitches: conflict-free over channels
-  constexpr int NA4 = TW / 8, NB4 = TW / 4, NH = 2;      // per thread: float4 of gz, float4 of u, halo scalars of u
+  constexpr int TW = 1 << TWL2, ORG = SP == 1 ? 1 : 0;
+  constexpr int PA = 2 * TW + 1;                          // odd pitches: conflict-free over channels
+  constexpr int BR = SP + 3, PWP = SP * (TW - 1) + 3;     // rows / columns of the shifted operand's patch
+  constexpr int PB = (BR * PWP) | 1;
+  // per thread: float4 of A; of B: float4 of the row interiors + the scalars left over
+  constexpr int NA4 = 64 * 2 * TW / 4 / 256;
+  constexpr int RV = SP == 1 ? TW / 4 : PWP / 4;          // float4 per patch row (SP 1: the aligned interior x0 .. x0+TW-1)
+  constexpr int RS = PWP - 4 * RV;                        // scalars per patch row (SP 1: the two halo columns)
+  constexpr int NB4 = (64 * BR * RV + 255) / 256, NBS = (64 * BR * RS + 255) / 256;
   extern __shared__ float smem[];
-  float* Gz = smem;               // [64][PA]   go, rows y0, y0+1                      (d applied at the operand fetch)
-  float* Us = smem + 64 * PA;     // [64][PB]   x,  rows y0-1 .. y0+2, columns x0-1 .. x0+TW   (s applied at the fetch)
+  float* As = smem;               // [64][PA]
+  float* Bs = smem + 64 * PA;     // [64][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int oq = wave >> 1, iq = wave & 1;
+  const int aq = wave >> 1, bq = wave & 1;
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int o_tile = lb % p.o_tiles;
-  const int i_tile = (lb / p.o_tiles) % p.i_tiles;
-  const int ks = lb / (p.o_tiles * p.i_tiles);
-  const int o0 = o_tile * 64, i0 = i_tile * 64;
-  const long long hw = (long long)p.h * p.w;
-  // rows of both tensors start 16-byte aligned and tiles never straddle the right edge inside a float4
-  const bool vec = (p.w & 3) == 0 && ((((uintptr_t)p.go) | ((uintptr_t)p.x)) & 15) == 0;
+  const int a_tile = lb % p.a_tiles;
+  const int b_tile = (lb / p.a_tiles) % p.b_tiles;
+  const int ks = lb / (p.a_tiles * p.b_tiles);
+  const int a0 = a_tile * 64, b0 = b_tile * 64;
+  const long long hwa = (long long)p.ha * p.wa, hwb = (long long)p.hb * p.wb;
+  // A rows start 16-byte aligned and a float4 never straddles the right edge (B is read with dword-aligned vectors)
+  const bool vec = (p.wa & 3) == 0 && (((uintptr_t)p.A) & 15) == 0 && (((uintptr_t)p.B) & 3) == 0;
 
   f32x16 acc[9];
 #pragma unroll
@@ -1198,96 +1209,116 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p
   // ---- staging plan: everything a tile step needs is loaded into registers while the previous step is on the
   // matrix pipe and written to LDS after the barrier (the forward kernel's register pipeline)
   f32x4 a4[NA4], b4[NB4];
-  float bh[NH], d_n = 1.f, s_n = 1.f, d_lane = 1.f, s_lane = 1.f;
-  const int my_o = o0 + oq * 32 + l31, my_i = i0 + iq * 32 + l31;
-  auto decode = [&](int tile, int& b, int& y0, int& x0) {
+  float bs[NBS], sa_n = 1.f, sb_n = 1.f, sa_lane = 1.f, sb_lane = 1.f;
+  const int my_a = a0 + aq * 32 + l31, my_b = b0 + bq * 32 + l31;
+  auto decode = [&](int tile, int& n, int& y0, int& x0) {
     const int tx = tile % p.tiles_x;
     const int ty = (tile / p.tiles_x) % p.tiles_y;
-    b = tile / (p.tiles_x * p.tiles_y);
+    n = tile / (p.tiles_x * p.tiles_y);
     y0 = ty * 2; x0 = tx * TW;
   };
+  // patch (row r, column c) of the shifted operand <-> its pixel
   auto issue = [&](int tile) {
-    int b, y0, x0;
-    decode(tile, b, y0, x0);
-    d_n = (p.d && my_o < p.cout) ? p.d[(long long)b * p.cout + my_o] : 1.f;
-    s_n = my_i < p.cin ? p.s[(long long)b * p.cin + my_i] : 0.f;
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+    sa_n = (p.sa && my_a < p.ca) ? p.sa[(long long)n * p.ca + my_a] : (my_a < p.ca ? 1.f : 0.f);
+    sb_n = (p.sb && my_b < p.cb) ? p.sb[(long long)n * p.cb + my_b] : (my_b < p.cb ? 1.f : 0.f);
     if (!vec) return;
 #pragma unroll
     for (int k = 0; k < NA4; ++k) {
       const int q = tid + 256 * k;
-      const int o = q / (2 * TW / 4), rem = q % (2 * TW / 4);
+      const int a = q / (2 * TW / 4), rem = q % (2 * TW / 4);
       const int y = y0 + rem / (TW / 4), x = x0 + 4 * (rem % (TW / 4));
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (o0 + o < p.cout && y < p.h && x < p.w)
-        v = *reinterpret_cast<const f32x4*>(p.go + ((long long)b * p.cout + o0 + o) * hw + (long long)y * p.w + x);
+      if (a0 + a < p.ca && y < p.ha && x < p.wa)
+        v = *reinterpret_cast<const f32x4*>(p.A + ((long long)n * p.ca + a0 + a) * hwa + (long long)y * p.wa + x);
       a4[k] = v;
     }
+    const int by0 = SP * y0 - ORG, bx0 = SP * x0 - ORG;
 #pragma unroll
     for (int k = 0; k < NB4; ++k) {
       const int q = tid + 256 * k;
-      const int i = q / TW, rem = q % TW;                 // 4 rows x TW/4 float4 per channel
-      const int y = y0 - 1 + rem / (TW / 4), x = x0 + 4 * (rem % (TW / 4));
+      const int b = q / (BR * RV), rem = q % (BR * RV);
+      const int y = by0 + rem / RV, c = (SP == 1 ? 1 : 0) + 4 * (rem % RV), x = bx0 + c;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i0 + i < p.cin && y >= 0 && y < p.h && x < p.w)
-        v = *reinterpret_cast<const f32x4*>(p.x + ((long long)b * p.cin + i0 + i) * hw + (long long)y * p.w + x);
+      if (q < 64 * BR * RV && b0 + b < p.cb && y >= 0 && y < p.hb) {
+        const float* src = p.B + ((long long)n * p.cb + b0 + b) * hwb + (long long)y * p.wb + x;
+        if (x >= 0 && x + 3 < p.wb) {
+          const f32x4_u t = *reinterpret_cast<const f32x4_u*>(src);
+          v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+        } else {
+          if (x + 0 >= 0 && x + 0 < p.wb) v.x = src[0];
+          if (x + 1 >= 0 && x + 1 < p.wb) v.y = src[1];
+          if (x + 2 >= 0 && x + 2 < p.wb) v.z = src[2];
+          if (x + 3 >= 0 && x + 3 < p.wb) v.w = src[3];
+        }
+      }
       b4[k] = v;
     }
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
+    for (int k = 0; k < NBS; ++k) {
       const int q = tid + 256 * k;
-      const int i = q >> 3, r = (q >> 1) & 3, side = q & 1;
-      const int y = y0 - 1 + r, x = side ? x0 + TW : x0 - 1;
-      bh[k] = (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w)
-                  ? p.x[((long long)b * p.cin + i0 + i) * hw + (long long)y * p.w + x] : 0.f;
+      const int b = q / (BR * RS), rem = q % (BR * RS);
+      const int r = rem / RS, e = rem % RS;
+      // SP 1: the two halo columns 0 and TW+1; SP 2: the column(s) after the last float4
+      const int c = SP == 1 ? (e ? TW + 1 : 0) : 4 * RV + e;
+      const int y = by0 + r, x = bx0 + c;
+      bs[k] = (q < 64 * BR * RS && b0 + b < p.cb && y >= 0 && y < p.hb && x >= 0 && x < p.wb)
+                  ? p.B[((long long)n * p.cb + b0 + b) * hwb + (long long)y * p.wb + x] : 0.f;
     }
   };
   auto commit = [&](int tile) {
-    d_lane = d_n; s_lane = s_n;
+    sa_lane = sa_n; sb_lane = sb_n;
     if (vec) {
 #pragma unroll
       for (int k = 0; k < NA4; ++k) {
         const int q = tid + 256 * k;
-        const int o = q / (2 * TW / 4), rem = q % (2 * TW / 4);
-        float* dst = Gz + o * PA + 4 * rem;                // (row r, column 4*c4) = r*TW + 4*c4 = 4*rem
+        const int a = q / (2 * TW / 4), rem = q % (2 * TW / 4);
+        float* dst = As + a * PA + 4 * rem;                // (row r, column 4*c4) = r*TW + 4*c4 = 4*rem
         dst[0] = a4[k].x; dst[1] = a4[k].y; dst[2] = a4[k].z; dst[3] = a4[k].w;
       }
 #pragma unroll
       for (int k = 0; k < NB4; ++k) {
         const int q = tid + 256 * k;
-        const int i = q / TW, rem = q % TW;
-        float* dst = Us + i * PB + (rem / (TW / 4)) * PWP + 1 + 4 * (rem % (TW / 4));
-        dst[0] = b4[k].x; dst[1] = b4[k].y; dst[2] = b4[k].z; dst[3] = b4[k].w;
+        if (q < 64 * BR * RV) {
+          const int b = q / (BR * RV), rem = q % (BR * RV);
+          float* dst = Bs + b * PB + (rem / RV) * PWP + (SP == 1 ? 1 : 0) + 4 * (rem % RV);
+          dst[0] = b4[k].x; dst[1] = b4[k].y; dst[2] = b4[k].z; dst[3] = b4[k].w;
+        }
       }
 #pragma unroll
-      for (int k = 0; k < NH; ++k) {
+      for (int k = 0; k < NBS; ++k) {
         const int q = tid + 256 * k;
-        const int i = q >> 3, r = (q >> 1) & 3, side = q & 1;
-        Us[i * PB + r * PWP + (side ? TW + 1 : 0)] = bh[k];
+        if (q < 64 * BR * RS) {
+          const int b = q / (BR * RS), rem = q % (BR * RS);
+          const int r = rem / RS, e = rem % RS;
+          Bs[b * PB + r * PWP + (SP == 1 ? (e ? TW + 1 : 0) : 4 * RV + e)] = bs[k];
+        }
       }
       return;
     }
     // widths that are no multiple of 4 / unaligned tensors: guarded scalar fill, not prefetched
-    int b, y0, x0;
-    decode(tile, b, y0, x0);
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
     for (int idx = tid; idx < 64 * 2 * TW; idx += 256) {
-      const int o = idx / (2 * TW), rc = idx - o * 2 * TW;
+      const int a = idx / (2 * TW), rc = idx - a * 2 * TW;
       const int y = y0 + (rc >> TWL2), x = x0 + (rc & (TW - 1));
       float v = 0.f;
-      if (o0 + o < p.cout && y < p.h && x < p.w) v = p.go[((long long)b * p.cout + o0 + o) * hw + (long long)y * p.w + x];
-      Gz[o * PA + rc] = v;
+      if (a0 + a < p.ca && y < p.ha && x < p.wa) v = p.A[((long long)n * p.ca + a0 + a) * hwa + (long long)y * p.wa + x];
+      As[a * PA + rc] = v;
     }
-    for (int idx = tid; idx < 64 * 4 * PWP; idx += 256) {
-      const int i = idx / (4 * PWP), q = idx - i * 4 * PWP;
-      const int y = y0 - 1 + q / PWP, x = x0 - 1 + q % PWP;
+    for (int idx = tid; idx < 64 * BR * PWP; idx += 256) {
+      const int b = idx / (BR * PWP), q = idx - b * BR * PWP;
+      const int y = SP * y0 - ORG + q / PWP, x = SP * x0 - ORG + q % PWP;
       float v = 0.f;
-      if (i0 + i < p.cin && y >= 0 && y < p.h && x >= 0 && x < p.w)
-        v = p.x[((long long)b * p.cin + i0 + i) * hw + (long long)y * p.w + x];
-      Us[i * PB + q] = v;
+      if (b0 + b < p.cb && y >= 0 && y < p.hb && x >= 0 && x < p.wb)
+        v = p.B[((long long)n * p.cb + b0 + b) * hwb + (long long)y * p.wb + x];
+      Bs[b * PB + q] = v;
     }
   };
 
-  const float* ga = Gz + (oq * 32 + l31) * PA + khalf * TW;
-  const float* ub = Us + (iq * 32 + l31) * PB + khalf * PWP;
+  const float* ga = As + (aq * 32 + l31) * PA + khalf * TW;
+  const float* ub = Bs + (bq * 32 + l31) * PB + SP * khalf * PWP;
   const int t_begin = ks * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
   if (t_begin < t_end) issue(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
@@ -1296,60 +1327,105 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (tile + 1 < t_end) issue(tile + 1);  // in flight during this step's MFMAs
-    // K-step j: pixels (y0 + khalf, x0 + j); tap (ky, kx) reads patch row khalf + ky, column j + kx.
-    float win[3][3];                       // win[ky][c % 3] = s * column c of patch row khalf + ky
+    // K-step j: A pixel (y0 + khalf, x0 + j); tap (ky, kx) reads patch row SP*khalf + ky, column SP*j + kx.
+    // The 3-column window slides by SP columns per step: column c lives in slot c % 3.
+    float win[3][3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) win[ky][c] = ub[ky * PWP + c] * s_lane;
-    float a_cur = ga[0] * d_lane, a_nxt = 0.f;
+      for (int c = 0; c < 3; ++c) win[ky][c] = ub[ky * PWP + c] * sb_lane;
+    float a_cur = ga[0] * sa_lane, a_nxt = 0.f;
 #pragma unroll
     for (int j = 0; j < TW; ++j) {
       __builtin_amdgcn_sched_barrier(0);
-      float nw[3] = {0.f, 0.f, 0.f};
+      float nw[3][SP];
       if (j + 1 < TW) {                    // operands of step j + 1 while step j is on the matrix pipe
         a_nxt = ga[j + 1];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) nw[ky] = ub[ky * PWP + j + 3];
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int e = 0; e < SP; ++e) nw[ky][e] = ub[ky * PWP + SP * j + 3 + e];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, win[ky][(j + kx) % 3], acc[ky * 3 + kx], 0, 0, 0);
+          acc[ky * 3 + kx] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, win[ky][(SP * j + kx) % 3], acc[ky * 3 + kx], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      a_cur = a_nxt * d_lane;
+      if (j + 1 < TW) {
+        a_cur = a_nxt * sa_lane;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) win[ky][j % 3] = nw[ky] * s_lane;   // column j leaves the window, column j + 3 enters
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int e = 0; e < SP; ++e) win[ky][(SP * j + e) % 3] = nw[ky][e] * sb_lane;   // columns SP*j .. leave, SP*j+3 .. enter
+      }
     }
   }
-  float* slab = p.partial + (long long)ks * 9 * p.cout * p.cin;
+  float* slab = p.partial + (long long)ks * 9 * p.ca * p.cb;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = o0 + oq * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      if (o < p.cout && my_i < p.cin) slab[((long long)t * p.cout + o) * p.cin + my_i] = acc[t][r];
+      const int a = a0 + aq * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (a < p.ca && my_b < p.cb) slab[((long long)t * p.ca + a) * p.cb + my_b] = acc[t][r];
     }
 }
 
-inline bool wgrad64_ok(int cin, int cout, int w) { return cin >= 48 && cout >= 48 && w >= 16; }
+// gw[o][i][t] = scale * sum_ks partial[ks][t][a][b];  transposed: (a, b) = (i, o), else (o, i)
+__global__ __launch_bounds__(256) void modconv_wgrad64_finish_f32(const float* __restrict__ partial, float* __restrict__ gw,
+                                                                  int cout, int cin, int ksplit, float scale, int transposed) {
+  const int total = cout * cin * 9;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int t = idx % 9, oi = idx / 9;
+    const int o = oi / cin, i = oi - o * cin;
+    const long long ab = transposed ? (long long)i * cout + o : (long long)o * cin + i;
+    float v = 0.f;
+    for (int ks = 0; ks < ksplit; ++ks) v += partial[((long long)ks * 9 + t) * cout * cin + ab];
+    gw[idx] = v * scale;
+  }
+}
 
-inline void wgrad64_plan(WG64Params& p) {
-  const int TW = p.w >= 32 ? 32 : 16;
-  p.tiles_x = (p.w + TW - 1) / TW;
-  p.tiles_y = (p.h + 1) / 2;
-  p.ntiles = p.batch * p.tiles_x * p.tiles_y;
-  p.o_tiles = (p.cout + 63) / 64;
-  p.i_tiles = (p.cin + 63) / 64;
-  const int pairs = p.o_tiles * p.i_tiles;
+// mode 0: plain conv; 1: transposed stride-2 conv (x [h,w], go [2h+1,2w+1]); 2: stride-2 valid conv (x [h,w], go [(h-3)/2+1, ..])
+inline bool wgrad64_setup(WG64Params& q, const float* go, const float* demod, const float* x, const float* style,
+                          int batch, int cin, int cout, int h, int w, int mode) {
+  if (cin < 48 || cout < 48) return false;
+  q.batch = batch;
+  if (mode == 0) {
+    q.A = go; q.sa = demod; q.ca = cout; q.ha = h; q.wa = w;
+    q.B = x; q.sb = style; q.cb = cin; q.hb = h; q.wb = w;
+  } else if (mode == 1) {
+    q.A = x; q.sa = style; q.ca = cin; q.ha = h; q.wa = w;
+    q.B = go; q.sb = demod; q.cb = cout; q.hb = 2 * h + 1; q.wb = 2 * w + 1;
+  } else {
+    if (h < 3 || w < 3) return false;
+    q.A = go; q.sa = demod; q.ca = cout; q.ha = (h - 3) / 2 + 1; q.wa = (w - 3) / 2 + 1;
+    q.B = x; q.sb = style; q.cb = cin; q.hb = h; q.wb = w;
+  }
+  if (q.wa < 16) return false;
+  const int TW = (mode == 0 && q.wa >= 32) ? 32 : 16;
+  q.tiles_x = (q.wa + TW - 1) / TW;
+  q.tiles_y = (q.ha + 1) / 2;
+  q.ntiles = batch * q.tiles_x * q.tiles_y;
+  q.a_tiles = (q.ca + 63) / 64;
+  q.b_tiles = (q.cb + 63) / 64;
+  const int pairs = q.a_tiles * q.b_tiles;
   int ks = (FMGAN_NUM_CU * 4 + pairs - 1) / pairs;      // ~2 rounds of 2 blocks per CU
-  const int max_ks = p.ntiles / 4 > 0 ? p.ntiles / 4 : 1; // at least 4 tile steps per block
+  const int max_ks = q.ntiles / 4 > 0 ? q.ntiles / 4 : 1; // at least 4 tile steps per block
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
-  p.tiles_per_split = (p.ntiles + ks - 1) / ks;
-  p.ksplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+  q.tiles_per_split = (q.ntiles + ks - 1) / ks;
+  q.ksplit = (q.ntiles + q.tiles_per_split - 1) / q.tiles_per_split;
+  return true;
+}
+
+template <int TWL2, int SP>
+inline void wgrad64_launch(const WG64Params& q, long long nblk, hipStream_t s) {
+  constexpr int TW = 1 << TWL2;
+  constexpr int PB = ((SP + 3) * (SP * (TW - 1) + 3)) | 1;
+  const size_t lds = sizeof(float) * 64 * ((2 * TW + 1) + PB);
+  hipLaunchKernelGGL((modconv_wgrad64_f32<TWL2, SP>), dim3((unsigned)nblk), dim3(256), lds, s, q);
 }
 
 inline void wgrad_plan(WGParams& p) {
@@ -1667,54 +1743,53 @@ extern "C" int fmgan_modconv2d_rgb_f32(const float* in, const float* wt, const f
                         fuse_act, alpha, act_scale, 0, 0, nullptr, 0, stream, &rgb);
 }
 
-extern "C" long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {
-  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w < 16) return 0;
-  if (wgrad64_ok(cin, cout, w)) {
-    WG64Params q{};
-    q.batch = batch; q.cin = cin; q.cout = cout; q.h = h; q.w = w;
-    wgrad64_plan(q);
+extern "C" long long fmgan_modconv_wgrad_mode_workspace_bytes(int batch, int cin, int cout, int h, int w, int mode) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || mode < 0 || mode > 2) return 0;
+  WG64Params q{};
+  if (wgrad64_setup(q, nullptr, nullptr, nullptr, nullptr, batch, cin, cout, h, w, mode))
     return (long long)q.ksplit * 9 * cout * cin * (long long)sizeof(float);
-  }
+  if (mode != 0 || w < 16) return 0;
   WGParams p{};
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
   wgrad_plan(p);
   return (long long)p.ksplit * 9 * cout * cin * (long long)sizeof(float);
 }
 
-extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, const float* x, const float* style,
-                                       float* gw, int batch, int cin, int cout, int h, int w, float scale,
-                                       void* workspace, long long workspace_bytes, void* stream) {
+extern "C" long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {
+  return fmgan_modconv_wgrad_mode_workspace_bytes(batch, cin, cout, h, w, 0);
+}
+
+extern "C" int fmgan_modconv_wgrad_mode_f32(const float* go, const float* demod, const float* x, const float* style,
+                                            float* gw, int batch, int cin, int cout, int h, int w, int mode, float scale,
+                                            void* workspace, long long workspace_bytes, void* stream) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return FMGAN_EINVAL;
-  if (w < 16) return FMGAN_EUNSUPPORTED;           // tiny layers: negligible FLOPs, the host keeps MIOpen's wgrad
+  if (mode < 0 || mode > 2) return FMGAN_EUNSUPPORTED;
   if (!go || !x || !style || !gw || !workspace) return FMGAN_EINVAL;
-  if ((long long)batch * (cin > cout ? cin : cout) * h * w >= (1LL << 40)) return FMGAN_EOVERFLOW;
-  if ((long long)h * w >= (1LL << 31) || cin > (1 << 20) || cout > (1 << 20)) return FMGAN_EOVERFLOW;
-  if (wgrad64_ok(cin, cout, w)) {
-    WG64Params q{};
-    q.go = go; q.d = demod; q.x = x; q.s = style; q.partial = (float*)workspace;
-    q.batch = batch; q.cin = cin; q.cout = cout; q.h = h; q.w = w;
-    wgrad64_plan(q);
+  // go is the largest tensor of the transposed conv: [batch, cout, 2h+1, 2w+1]
+  const long long big_hw = mode == 1 ? (long long)(2 * h + 1) * (2 * w + 1) : (long long)h * w;
+  if ((long long)batch * (cin > cout ? cin : cout) * big_hw >= (1LL << 40)) return FMGAN_EOVERFLOW;
+  if (big_hw >= (1LL << 31) || cin > (1 << 20) || cout > (1 << 20)) return FMGAN_EOVERFLOW;
+  hipStream_t s = (hipStream_t)stream;
+  WG64Params q{};
+  if (wgrad64_setup(q, go, demod, x, style, batch, cin, cout, h, w, mode)) {
+    q.partial = (float*)workspace;
     if (workspace_bytes < (long long)q.ksplit * 9 * cout * cin * (long long)sizeof(float)) return FMGAN_EINVAL;
-    const long long nblk = (long long)q.o_tiles * q.i_tiles * q.ksplit;
+    const long long nblk = (long long)q.a_tiles * q.b_tiles * q.ksplit;
     if (nblk > 0x7fffffffLL) return FMGAN_EOVERFLOW;
-    hipStream_t st_ = (hipStream_t)stream;
-    if (w >= 32) {
-      constexpr int TW = 32;
-      const size_t lds = sizeof(float) * 64 * ((2 * TW + 1) + (4 * (TW + 2) + 1));
-      hipLaunchKernelGGL((modconv_wgrad64_f32<5>), dim3((unsigned)nblk), dim3(256), lds, st_, q);
+    if (mode == 0) {
+      if (q.wa >= 32) wgrad64_launch<5, 1>(q, nblk, s); else wgrad64_launch<4, 1>(q, nblk, s);
     } else {
-      constexpr int TW = 16;
-      const size_t lds = sizeof(float) * 64 * ((2 * TW + 1) + (4 * (TW + 2) + 1));
-      hipLaunchKernelGGL((modconv_wgrad64_f32<4>), dim3((unsigned)nblk), dim3(256), lds, st_, q);
+      wgrad64_launch<4, 2>(q, nblk, s);
     }
-    int st2 = fmgan_check_launch();
-    if (st2 != FMGAN_OK) return st2;
-    int fb2 = (cout * cin * 9 + 255) / 256;
-    if (fb2 > FMGAN_NUM_CU * 16) fb2 = FMGAN_NUM_CU * 16;
-    hipLaunchKernelGGL(modconv_wgrad_finish_f32, dim3(fb2), dim3(256), 0, st_, (const float*)workspace, gw, cout, cin,
-                       q.ksplit, scale);
+    int st = fmgan_check_launch();
+    if (st != FMGAN_OK) return st;
+    int fb = (cout * cin * 9 + 255) / 256;
+    if (fb > FMGAN_NUM_CU * 16) fb = FMGAN_NUM_CU * 16;
+    hipLaunchKernelGGL(modconv_wgrad64_finish_f32, dim3(fb), dim3(256), 0, s, (const float*)workspace, gw, cout, cin,
+                       q.ksplit, scale, mode == 1 ? 1 : 0);
     return fmgan_check_launch();
   }
+  if (mode != 0 || w < 16) return FMGAN_EUNSUPPORTED;   // narrow / tiny layers: the host keeps MIOpen's wgrad
   WGParams p{};
   p.go = go; p.d = demod; p.x = x; p.s = style; p.partial = (float*)workspace;
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
@@ -1727,7 +1802,6 @@ extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, cons
   if (lds < sizeof(float) * 4 * 32 * 33) lds = sizeof(float) * 4 * 32 * 33;
   const long long blocks = (long long)p.o_tiles * p.i_tiles * p.ksplit;
   if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
-  hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(modconv_wgrad_f32, dim3((unsigned)blocks), dim3(256), lds, s, p);
   int st = fmgan_check_launch();
   if (st != FMGAN_OK) return st;
@@ -1736,6 +1810,14 @@ extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, cons
   hipLaunchKernelGGL(modconv_wgrad_finish_f32, dim3(fb), dim3(256), 0, s, (const float*)workspace, gw, cout, cin,
                      p.ksplit, scale);
   return fmgan_check_launch();
+}
+
+extern "C" int fmgan_modconv_wgrad_f32(const float* go, const float* demod, const float* x, const float* style,
+                                       float* gw, int batch, int cin, int cout, int h, int w, float scale,
+                                       void* workspace, long long workspace_bytes, void* stream) {
+  if (w > 0 && w < 16) return FMGAN_EUNSUPPORTED;           // tiny layers: negligible FLOPs, the host keeps MIOpen's wgrad
+  return fmgan_modconv_wgrad_mode_f32(go, demod, x, style, gw, batch, cin, cout, h, w, 0, scale, workspace,
+                                      workspace_bytes, stream);
 }
 
 extern "C" int fmgan_torgb_f32(const float* in, const float* weight, const float* style, const float* bias,

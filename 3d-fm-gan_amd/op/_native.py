@@ -55,6 +55,8 @@ def lib():
     _sig(L.fmgan_modconv2d_rgb_f32, [vp] * 5 + [i] * 5 + [vp] * 3 + [i, i, f, f] + [vp] * 4 + [i, vp])
     _sig(L.fmgan_modconv_wgrad_workspace_bytes, [i] * 5, ll)
     _sig(L.fmgan_modconv_wgrad_f32, [vp] * 5 + [i] * 5 + [f, vp, ll, vp])
+    _sig(L.fmgan_modconv_wgrad_mode_workspace_bytes, [i] * 6, ll)
+    _sig(L.fmgan_modconv_wgrad_mode_f32, [vp] * 5 + [i] * 6 + [f, vp, ll, vp])
     _sig(L.fmgan_images_to_tensor, [vp, vp, i, i, i, f, f, vp])
     _sig(L.fmgan_resize_output_size, [i, i, i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)])
     _sig(L.fmgan_resize_plan_ints, [i] * 4, ll)
@@ -351,21 +353,24 @@ def modconv2d_rgb(x, wt, style, demod, noise, noise_weight, bias, alpha, act_sca
     return out, rgb
 
 
-def modconv_wgrad(go, demod, x, style, scale):
-    """Conv part of the weight gradient of the plain modulated conv -> [cout,cin,3,3]; None if the shape is not
-    served by the kernel (w < 16)."""
+def modconv_wgrad(go, demod, x, style, scale, fast_only=False, mode=0):
+    """Conv part of the weight gradient of the modulated conv (mode as in modconv2d; x is the conv's input, go the
+    gradient of its output) -> [cout,cin,3,3]; None if the shape is not served by the kernel, or — with fast_only — not
+    by its 64 x 64-tile form (>= 48 channels on both sides)."""
     go, x, style = go.contiguous(), x.contiguous(), style.contiguous()
-    b, cout, h, w = go.shape
-    cin = x.shape[1]
-    ws_bytes = lib().fmgan_modconv_wgrad_workspace_bytes(b, cin, cout, h, w)
+    b, cout = go.shape[:2]
+    cin, h, w = x.shape[1:]
+    if (fast_only or mode != 0) and (cin < 48 or cout < 48):
+        return None
+    ws_bytes = lib().fmgan_modconv_wgrad_mode_workspace_bytes(b, cin, cout, h, w, int(mode))
     if ws_bytes == 0:
         return None
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     gw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     with on_device(x) as stream:
-        tok = _observer.begin('modconv_wgrad', (b, cin, cout, h, w))
-        check(lib().fmgan_modconv_wgrad_f32(ptr(go), ptr(demod), ptr(x), ptr(style), ptr(gw), b, cin, cout, h, w,
-                                            float(scale), ptr(ws), ws_bytes, stream), 'modconv_wgrad')
+        tok = _observer.begin('modconv_wgrad', (b, cin, cout, h, w, int(mode)))
+        check(lib().fmgan_modconv_wgrad_mode_f32(ptr(go), ptr(demod), ptr(x), ptr(style), ptr(gw), b, cin, cout, h, w,
+                                                 int(mode), float(scale), ptr(ws), ws_bytes, stream), 'modconv_wgrad')
         _observer.end(tok)
     return gw
 

@@ -19,9 +19,12 @@ from torch.nn import functional as F
 
 from . import _native
 
-# Weight gradient of the plain conv: MIOpen's fp32 wgrad measures 105-112 TFLOP/s on MI355X, this repo's
-# fmgan_modconv_wgrad_f32 50 TFLOP/s (synchronous staging; bit-reproducible) — MIOpen is the default.
-HIP_WGRAD = os.environ.get('FMGAN_HIP_WGRAD', '0') == '1'
+# Weight gradient of the plain conv: this repo's fmgan_modconv_wgrad_f32 (64 x 64 tile, sliding 3 x 3 window,
+# register-prefetch pipeline; bit-reproducible) measures 111-123 TFLOP/s on MI355X against 96-116 for MIOpen's fp32
+# wgrad on the same layers (profiles/r02_backward_layers.txt) and is the default wherever it applies (>= 48 channels on
+# both sides, >= 16 pixels per row), for the plain, the transposed and the stride-2 conv; FMGAN_HIP_WGRAD=0 selects
+# MIOpen everywhere.
+HIP_WGRAD = os.environ.get('FMGAN_HIP_WGRAD', '1') != '0'
 COMPOSITE_MIOPEN = os.environ.get('FMGAN_COMPOSITE_MIOPEN', '0') == '1'
 
 
@@ -73,9 +76,12 @@ def _kernel_conv(u, w4, mode, kind):
 def _wgrad(u, g, mode):
     """G_m(u, g) -> [cout, cin, 3, 3].  mode 0 on this repo's MFMA wgrad kernel when enabled, else MIOpen's fp32 wgrad."""
     cout, cin = g.shape[1], u.shape[1]
+    if HIP_WGRAD and u.dtype == torch.float32:
+        gw = _native.modconv_wgrad(g, None, u, _ones(u.shape[0], cin, u.device), 1.0, fast_only=True, mode=mode)
+        if gw is not None:
+            return gw
     if mode == 0:
-        gw = _native.modconv_wgrad(g, None, u, _ones(u.shape[0], cin, u.device), 1.0) if HIP_WGRAD else None
-        return gw if gw is not None else torch.nn.grad.conv2d_weight(u, (cout, cin, 3, 3), g, padding=1)
+        return torch.nn.grad.conv2d_weight(u, (cout, cin, 3, 3), g, padding=1)
     if mode == 1:   # y = conv_transpose2d(u, W^T, stride 2): adjoint of conv2d(., W^T, stride 2)
         return torch.nn.grad.conv2d_weight(g, (cin, cout, 3, 3), u, stride=2).transpose(0, 1)
     return torch.nn.grad.conv2d_weight(u, (cout, cin, 3, 3), g, stride=2)
@@ -221,7 +227,7 @@ class ModulatedConv2dFunction(Function):
             if need[2]:
                 gs = gs + (2.0 * scale * scale) * s * (gq @ wsq)
         if need[1]:
-            gw = _native.modconv_wgrad(go, d, x, s, scale) if (mode == 0 and HIP_WGRAD) else None
+            gw = _native.modconv_wgrad(go, d, x, s, scale, fast_only=True, mode=mode) if HIP_WGRAD else None
             if gw is None:
                 gz = go * d[:, :, None, None] if demodulate else go
                 u = x * s[:, :, None, None]

@@ -270,6 +270,19 @@ int fmgan_modconv2d_rgb_f32(const float *in, const float *wt, const float *style
  *   finish, bit-reproducible).  w < 16 returns FMGAN_EUNSUPPORTED (0 workspace bytes): tiny layers stay on MIOpen.
  */
 long long fmgan_modconv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w);
+/*
+ * The same for every mode of fmgan_modconv2d_f32 (h, w = the conv INPUT's size; go has that mode's output size):
+ *   mode 1 (transposed, go [batch,cout,2h+1,2w+1]):  gw[o,i,ky,kx] = scale * sum (demod*go)[b,o,2y+ky,2x+kx] * (style*x)[b,i,y,x]
+ *   mode 2 (stride 2,   go [batch,cout,(h-3)/2+1,(w-3)/2+1]):  ... sum (demod*go)[b,o,y,x] * (style*x)[b,i,2y+ky,2x+kx]
+ * 64 x 64 output tiles whose four waves walk the same 2 x TW pixels per step; an MFMA's pixel pair comes from the two
+ * rows, so consecutive K-steps move one pixel along x and the 3 x 3 window of the shifted operand slides (SP new
+ * LDS reads per tap row and step).  Served: >= 48 channels on both sides and >= 16 pixels per row of the unshifted
+ * operand (mode 0 also the 32 x 32-tile kernel for narrower layers); otherwise FMGAN_EUNSUPPORTED / 0 bytes.
+ */
+long long fmgan_modconv_wgrad_mode_workspace_bytes(int batch, int cin, int cout, int h, int w, int mode);
+int fmgan_modconv_wgrad_mode_f32(const float *go, const float *demod, const float *x, const float *style,
+                                 float *gw, int batch, int cin, int cout, int h, int w, int mode, float scale,
+                                 void *workspace, long long workspace_bytes, void *stream);
 int fmgan_modconv_wgrad_f32(const float *go, const float *demod, const float *x, const float *style,
                             float *gw, int batch, int cin, int cout, int h, int w, float scale,
                             void *workspace, long long workspace_bytes, void *stream);

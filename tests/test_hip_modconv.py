@@ -484,3 +484,28 @@ def test_create_graph_path_runs_on_hip_kernels():
         _native.set_observer(None)
     assert first >= 2, obs.n       # recomputed forward C + data gradient D on the MFMA kernel
     assert second >= 2, obs.n      # their derivatives, again on the MFMA kernel
+
+
+@pytest.mark.parametrize('shape', [
+    # (mode, b, cin, cout, h, w) with h, w the conv input's size: transposed (mode 1) and stride-2 (mode 2) weight gradients
+    (1, 2, 64, 64, 16, 16), (1, 1, 128, 64, 32, 32), (1, 3, 100, 50, 17, 20), (1, 2, 512, 256, 64, 64),
+    (2, 2, 64, 96, 35, 35), (2, 1, 70, 130, 40, 66), (2, 2, 128, 128, 129, 129)])
+def test_strided_wgrad_kernel_vs_fp64(shape):
+    """fmgan_modconv_wgrad_mode_f32 for the transposed and the stride-2 conv vs float64 autograd of the dense conv."""
+    from op import _native
+    import torch.nn.functional as F
+    mode, b, cin, cout, h, w = shape
+    x = synth.tensor(f'swg/{shape}/x', (b, cin, h, w)).to(dev())
+    s = synth.tensor(f'swg/{shape}/s', (b, cin), shift=1.0, scale=0.5).to(dev())
+    d = synth.tensor(f'swg/{shape}/d', (b, cout), shift=1.0, scale=0.3).to(dev())
+    oh, ow = (2 * h + 1, 2 * w + 1) if mode == 1 else ((h - 3) // 2 + 1, (w - 3) // 2 + 1)
+    go = synth.tensor(f'swg/{shape}/go', (b, cout, oh, ow)).to(dev())
+    gw = _native.modconv_wgrad(go, d, x, s, 0.37, mode=mode)
+    assert gw is not None
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=dev(), requires_grad=True)
+    u64, g64 = (x * s[:, :, None, None]).double(), (go * d[:, :, None, None]).double()
+    y = F.conv_transpose2d(u64, wref.transpose(0, 1), stride=2) if mode == 1 else F.conv2d(u64, wref, stride=2)
+    ref, = torch.autograd.grad(y, wref, g64)
+    ref = ref * 0.37
+    torch.testing.assert_close(gw.double(), ref, atol=2e-5 * float(ref.abs().max()), rtol=2e-5)
+    assert torch.equal(gw, _native.modconv_wgrad(go, d, x, s, 0.37, mode=mode))      # bit-reproducible

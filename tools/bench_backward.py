@@ -35,8 +35,11 @@ for (cin, cout, h, mode) in ((512, 512, 32, 0), (512, 512, 64, 0), (256, 256, 12
     th, tc, tf = t(hip), t(comp), t(fwd)
     print(f'mode {mode} {cin}->{cout} @{h}^2 B={B}: fwd {tf:.2f} ms | fwd+bwd HIP {th:.2f} ms ({3*fl/th:.0f} GF/ms-equiv) | composite {tc:.2f} ms')
     # wgrad alone
+    oh = h if mode == 0 else 2 * h + 1
+    go = torch.randn(B, cout, oh, oh, device=d); dm = torch.rand(B, cout, device=d) + 0.5
+    tw = t(lambda: _native.modconv_wgrad(go, dm, x.detach(), s.detach(), scale, mode=mode))
     if mode == 0:
-        go = torch.randn(B, cout, h, h, device=d); dm = torch.rand(B, cout, device=d) + 0.5
-        tw = t(lambda: _native.modconv_wgrad(go, dm, x.detach(), s.detach(), scale))
         tm = t(lambda: torch.nn.grad.conv2d_weight(x.detach() * s.detach()[:, :, None, None], (cout, cin, 3, 3), go * dm[:, :, None, None], padding=1))
-        print(f'     wgrad: HIP {tw:.2f} ms ({fl/tw:.1f} TF) | MIOpen conv2d_weight {tm:.2f} ms ({fl/tm:.1f} TF)')
+    else:
+        tm = t(lambda: torch.nn.grad.conv2d_weight(go * dm[:, :, None, None], (cin, cout, 3, 3), x.detach() * s.detach()[:, :, None, None], stride=2))
+    print(f'     wgrad: HIP {tw:.2f} ms ({fl/tw:.1f} TF) | MIOpen conv2d_weight {tm:.2f} ms ({fl/tm:.1f} TF)')
