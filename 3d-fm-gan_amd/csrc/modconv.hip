@@ -845,6 +845,7 @@ inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
 }
 
 constexpr size_t MC_LDS_LIMIT = 64 * 1024;   // dynamic LDS a launch may ask for without a function attribute
+constexpr size_t MC_LDS_MAX = 160 * 1024;    // LDS of a CU
 
 // Returns FMGAN_OK, an error, or +1 when this variant cannot serve the shape (PIPE 1 with an LDS image over the limit):
 // the caller then launches the register-pipeline variant.
@@ -874,7 +875,19 @@ int launch_cfg(MCParams& p, hipStream_t s) {
     p.lds_patch_floats = (int)((patch + 63) / 64 * 64);
     p.lds_buf_floats = KC * 9 * BM + p.lds_patch_floats + (int)((nbmax * KC + 63) / 64 * 64);
     lds = sizeof(float) * 2 * (size_t)p.lds_buf_floats;
-    if (lds > MC_LDS_LIMIT) return 1;
+    if (lds > (MINB == 1 ? MC_LDS_MAX : MC_LDS_LIMIT)) return 1;
+    if (lds > MC_LDS_LIMIT) {
+      // one block per CU may use more than the 64 KB a launch gets by default (160 KB per CU on gfx950)
+      static bool raised = false;
+      if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_mfma_f32<MODE, RM, RNP, WM, WN, false, MINB, KC, PIPE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_MAX) != hipSuccess) {
+          (void)hipGetLastError();
+          return 1;
+        }
+        raised = true;
+      }
+    }
   }
   if constexpr (MODE == 0) {
     if (p.rgb_out) {
@@ -901,7 +914,7 @@ inline char mc_variant(int mode, int cfg) {
         char name[32];
         snprintf(name, sizeof(name), "FMGAN_MC_V%d%d", m, c);
         const char* e = getenv(name);
-        table[m][c] = (e && (e[0] == 'A' || e[0] == 'B' || e[0] == 'C')) ? e[0] : defaults[m][c];
+        table[m][c] = (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] : defaults[m][c];
       }
     init = true;
   }
@@ -960,6 +973,7 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
       case 0:
         if (v == 'B') st = launch_cfg<0, 2, 2, 2, 2, 3, 4, 1>(p, s);
         else if (v == 'C') st = launch_cfg<0, 4, 2, 1, 4, 2, 4, 1>(p, s);                      // 128 x 256: 0.75 reads / MFMA
+        else if (v == 'D' && !p.rgb_out && p.ksplit == 1) st = launch_cfg<0, 4, 4, 2, 2, 1, 4, 1>(p, s);   // 256 x 256, one wave per SIMD
         return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
       case 1:
         if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);

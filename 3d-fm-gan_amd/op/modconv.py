@@ -22,9 +22,10 @@ from . import _native
 # Weight gradient of the plain conv: this repo's fmgan_modconv_wgrad_f32 (64 x 64 tile, sliding 3 x 3 window,
 # register-prefetch pipeline; bit-reproducible) measures 111-123 TFLOP/s on MI355X against 96-116 for MIOpen's fp32
 # wgrad on the same layers (profiles/r02_backward_layers.txt) and is the default wherever it applies (>= 48 channels on
-# both sides, >= 16 pixels per row), for the plain, the transposed and the stride-2 conv; FMGAN_HIP_WGRAD=0 selects
-# MIOpen everywhere.
-HIP_WGRAD = os.environ.get('FMGAN_HIP_WGRAD', '1') != '0'
+# both sides, >= 16 pixels per row).  Its stride-2 forms (transposed / downsampling conv: 16-pixel steps, 7 LDS reads per 9
+# MFMAs) measure 60-63 TFLOP/s against MIOpen's 79-95 and are opt-in.  FMGAN_HIP_WGRAD: 0 = MIOpen everywhere,
+# 1 (default) = own kernel for the plain conv, 2 = own kernel for every mode.
+HIP_WGRAD = int(os.environ.get('FMGAN_HIP_WGRAD', '1'))
 COMPOSITE_MIOPEN = os.environ.get('FMGAN_COMPOSITE_MIOPEN', '0') == '1'
 
 
@@ -76,7 +77,7 @@ def _kernel_conv(u, w4, mode, kind):
 def _wgrad(u, g, mode):
     """G_m(u, g) -> [cout, cin, 3, 3].  mode 0 on this repo's MFMA wgrad kernel when enabled, else MIOpen's fp32 wgrad."""
     cout, cin = g.shape[1], u.shape[1]
-    if HIP_WGRAD and u.dtype == torch.float32:
+    if (HIP_WGRAD >= 2 or (HIP_WGRAD == 1 and mode == 0)) and u.dtype == torch.float32:
         gw = _native.modconv_wgrad(g, None, u, _ones(u.shape[0], cin, u.device), 1.0, fast_only=True, mode=mode)
         if gw is not None:
             return gw
@@ -227,7 +228,8 @@ class ModulatedConv2dFunction(Function):
             if need[2]:
                 gs = gs + (2.0 * scale * scale) * s * (gq @ wsq)
         if need[1]:
-            gw = _native.modconv_wgrad(go, d, x, s, scale, fast_only=True, mode=mode) if HIP_WGRAD else None
+            hip_w = HIP_WGRAD >= 2 or (HIP_WGRAD == 1 and mode == 0)
+            gw = _native.modconv_wgrad(go, d, x, s, scale, fast_only=True, mode=mode) if hip_w else None
             if gw is None:
                 gz = go * d[:, :, None, None] if demodulate else go
                 u = x * s[:, :, None, None]

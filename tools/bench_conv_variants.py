@@ -9,6 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANTS = os.environ.get('FMGAN_BENCH_VARIANTS', 'ABC')
 LAYERS = [(4, 512, 512, 0), (4, 512, 512, 1), (8, 512, 512, 0), (8, 512, 512, 1), (16, 512, 512, 0), (16, 512, 512, 1),
           (32, 512, 512, 0), (32, 512, 512, 1), (64, 512, 512, 0), (64, 512, 256, 1), (128, 256, 256, 0), (128, 256, 128, 1),
           (256, 128, 128, 0), (256, 128, 64, 1), (512, 64, 64, 0), (512, 64, 32, 1), (1024, 32, 32, 0)]
@@ -73,7 +74,7 @@ def main():
 
 def table(batch):
     res = {}
-    for v in 'ABC':
+    for v in VARIANTS:
         env = dict(os.environ)
         for m in range(3):
             for c in range(3):
@@ -85,8 +86,8 @@ def table(batch):
             print(f'variant {v} failed:\n{pr.stderr[-2000:]}')
             continue
         res[v] = json.loads(line[0][7:])
-    print(f'| layer (B={batch}) | mode | A us | B us | C us | best | TFLOP/s best | bits equal |')
-    print('|---|---|---|---|---|---|---|---|')
+    print(f'| layer (B={batch}) | mode | ' + ' | '.join(f'{v} us' for v in VARIANTS) + ' | best | TFLOP/s best | bits equal |')
+    print('|---|---|' + '---|' * len(VARIANTS) + '---|---|---|')
     tot = {v: 0.0 for v in res}
     best_tot = 0.0
     flops_tot = 0.0
@@ -100,9 +101,9 @@ def table(batch):
         best_tot += us[bv]
         flops_tot += fl
         ghz = res[bv][i].get('ghz')
-        print(f"| {r}^2 {cin}->{cout} | {mode} | " + ' | '.join(f"{us.get(v, float('nan')):.1f}" for v in 'ABC') +
+        print(f"| {r}^2 {cin}->{cout} | {mode} | " + ' | '.join(f"{us.get(v, float('nan')):.1f}" for v in VARIANTS) +
               f" | {bv} | {fl / us[bv] / 1e6:.1f} | {'yes' if same else 'NO'} |" + (f' clock {ghz:.2f} GHz' if ghz else ''))
-    print(f"| total | | " + ' | '.join(f"{tot.get(v, float('nan')):.0f}" for v in 'ABC') + f" | {best_tot:.0f} | {flops_tot / best_tot / 1e6:.1f} | |")
+    print(f"| total | | " + ' | '.join(f"{tot.get(v, float('nan')):.0f}" for v in VARIANTS) + f" | {best_tot:.0f} | {flops_tot / best_tot / 1e6:.1f} | |")
 
 
 if __name__ == '__main__':
