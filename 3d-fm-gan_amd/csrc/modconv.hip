@@ -914,7 +914,7 @@ inline char mc_variant(int mode, int cfg) {
         char name[32];
         snprintf(name, sizeof(name), "FMGAN_MC_V%d%d", m, c);
         const char* e = getenv(name);
-        table[m][c] = (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] : defaults[m][c];
+        table[m][c] = (e && e[0] >= 'A' && e[0] <= 'C') ? e[0] : defaults[m][c];
       }
     init = true;
   }
@@ -973,7 +973,6 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
       case 0:
         if (v == 'B') st = launch_cfg<0, 2, 2, 2, 2, 3, 4, 1>(p, s);
         else if (v == 'C') st = launch_cfg<0, 4, 2, 1, 4, 2, 4, 1>(p, s);                      // 128 x 256: 0.75 reads / MFMA
-        else if (v == 'D' && !p.rgb_out && p.ksplit == 1) st = launch_cfg<0, 4, 4, 2, 2, 1, 4, 1>(p, s);   // 256 x 256, one wave per SIMD
         return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
       case 1:
         if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);

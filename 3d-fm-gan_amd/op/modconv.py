@@ -8,8 +8,8 @@ autograd over F.conv2d / F.conv_transpose2d.  Here:
   * create_graph=True: the backward re-states the op in the input-modulated form  d (.) C(x (.) s, scale W)  whose
     dense contraction C is the DenseConv / DenseConvDgrad / DenseConvWgrad family — three autograd Functions on the
     MFMA kernel that differentiate into each other (the way the reference nests UpFirDn2d / UpFirDn2dBackward,
-    op/upfirdn2d.py:28-94), so every derivative order runs this repo's kernels; only the weight-gradient primitive
-    is MIOpen's wgrad unless FMGAN_HIP_WGRAD=1.
+    op/upfirdn2d.py:28-94), so every derivative order runs this repo's kernels (the stride-2 weight-gradient
+    primitive is MIOpen's unless FMGAN_HIP_WGRAD=2).
 """
 import os
 
@@ -177,8 +177,8 @@ class ModulatedConv2dFunction(Function):
         d/dx of mode 0:  g_u = conv(go * d, W^T flipped)            -> mode 0 with weight layout kind 1
         d/dx of mode 1:  g_u = stride-2 conv(go * d, W^T)           -> mode 2 with weight layout kind 2
     where u = x * s is the modulated input and the factor d (demodulation) rides as the kernel's input modulation;
-    g_x = g_u * s.  The weight gradient is MIOpen's wgrad on (u, go*d) (an MFMA kernel of this repo exists,
-    fmgan_modconv_wgrad_f32, but is half as fast — see HIP_WGRAD).  The demodulation chain rule is small
+    g_x = g_u * s.  The weight gradient of the plain conv is fmgan_modconv_wgrad_mode_f32 (see HIP_WGRAD), of the
+    transposed conv MIOpen's wgrad on (u, go*d).  The demodulation chain rule is small
     [B,Cout]x[Cout,Cin] algebra.  When a graph is requested (R1 / path-length regularisers), the whole
     backward is the differentiable composite instead.
     """
