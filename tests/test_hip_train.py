@@ -15,7 +15,9 @@ fixture would be either vacuous or flaky.  Each tensor is therefore held to
 i.e. "no farther from the exact value than the reference itself, up to a small factor".  The floors are the measured
 worst cases (profiles/r02_parity_errors.md, tools/measure_parity.py) times ~3: tensors whose gradient this repo's
 kernels and torch reductions produce 1e-3 (measured 2.3e-4), encoder tensors whose weight gradients come from MIOpen's
-fp32 wgrad kernels 6e-3 (measured 2.0e-3 on resnet conv1.weight, 1.3e-3 on a pSp head conv; their norms agree to 4e-5).
+fp32 wgrad kernels 2e-2: those are not run-to-run reproducible and put isolated elements 1.3e-3 ... 6.2e-3 of the tensor's
+max away from the float64 value (resnet conv1.weight 2.0e-3, pSp head convs 1.3e-3 and 6.2e-3 in three runs of the same
+binary), while the tensors' norms agree to 4e-5 (checked with the tight norm floor).
 """
 import os
 import sys
@@ -31,7 +33,7 @@ import synth
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-MARGIN, FLOOR, FLOOR_MIOPEN, FLOOR_NORM, FLOOR_SCALAR = 4.0, 1e-3, 6e-3, 5e-4, 8e-3
+MARGIN, FLOOR, FLOOR_MIOPEN, FLOOR_NORM, FLOOR_SCALAR = 4.0, 1e-3, 2e-2, 5e-4, 8e-3
 
 
 def dev():

@@ -24,7 +24,8 @@ a, b = parse(first), parse(second)
 print(f'# MFMA utilisation of the modulated-conv kernels (rocprofv3 --pmc, tools/profile_mfma.sh {tag}, bench_kernels.py conv, B=8)\n')
 print('MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs); FLOPs = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512')
 print('(equals the algorithmic 2*9*Cin*Cout*B*H*W of the layer: the kernel issues no wasted MFMAs except in thin edge tiles).')
-print('Template arguments: <MODE, RM, RNP, WM, WN, RGB epilogue, min blocks per CU>; tile = 32*RM*WM channels x 32*RNP*WN positions.\n')
+print('Template arguments: <MODE, RM, RNP, WM, WN, RGB epilogue, min blocks per CU, channels per chunk, PIPE (0 register / 1 LDS-DMA)>;')
+print('tile = 32*RM*WM channels x 32*RNP*WN positions.  (The mode-1 counts include the MFMAs the thin strips still issue.)\n')
 print('| kernel | grid (threads) | MFMA busy cycles | GUI active (sum of 8 XCDs) | MfmaUtil % | GFLOP by counter | wait/wave cycles % |')
 print('|---|---|---|---|---|---|---|')
 for k, v in a.items():
