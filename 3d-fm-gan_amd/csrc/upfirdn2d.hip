@@ -22,11 +22,14 @@
 //    out-of-range columns.  (A per-element guarded path for those lanes cost 15 %: 527 -> 451 us.)
 //    fmgan_upfirdn2d_strided lets the producer hand over rows padded to a 128-byte multiple with the
 //    first tap column on a 16-byte boundary (op/_native.py::aligned_rows_buffer): 415 us = 5.18 TB/s.
+//    Path 1b (aligned-row inputs, i.e. every large blur of the synthesis network) replaces the register staging by an
+//    LDS-DMA ring: 3 rows in flight per wave at 8 waves/SIMD, one hand-counted s_waitcnt per step (see ufd_dmaring_f32).
 //  * Path 2 ("plane-tile") stages whole small planes (<= ~110x110) in LDS with one flat coalesced
 //    copy: at 4..64 px the planes are too narrow for a wave-wide strip.
 //  * Path 3 (up=2 polyphase, the ToRGB skip upsample): 2x4 outputs per thread, only the 2x2 taps
 //    that meet a non-zero sample of the zero-stuffed input are visited; store-bound.
 //  * Path 0 is the generic fallback (any up/down/pad/kernel/minor, f32/f64/f16).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -310,6 +313,198 @@ __global__ __launch_bounds__(256) void ufd_rowmarch_f32(const float* __restrict_
 #undef FINISH
 }
 
+
+// ---------------------------------------------------------------- path 1b: row-march through an LDS-DMA ring
+// Same blocking as path 1 (a wave marches TH rows of a 256-column strip), for inputs in the aligned-row layout
+// (op/_native.py::aligned_rows_buffer: the first tap column of every row on a 16-byte boundary, pitch % 4 == 0):
+//  * a row segment goes HBM -> LDS with `buffer_load_dwordx4 ... lds` (+ one dword DMA for the 3 columns past lane 63):
+//    no staging VGPRs, no address VALU (the lane offsets are row-invariant, the row is the SGPR soffset), rows outside
+//    the image are zero-filled by the buffer range check.  4 slots per wave = 3 rows in flight ahead of the row being
+//    filtered, at 46-52 VGPRs (8 waves/SIMD; path 1 holds 2 rows in flight at 114 VGPRs, 4 waves/SIMD);
+//  * the wave synchronises with ITSELF only: `s_waitcnt vmcnt(N)`, N = the number of VMEM operations issued after the
+//    wanted row's DMAs (returns are in order), a compile-time constant of the step because every step issues the same
+//    operations (noise request, 2 DMAs, store) — partial tiles, whose steps skip stores, wait for vmcnt(0) instead;
+//  * a lane's 7-column window is two ds_read_b128: the halo columns are simply the next lane's first floats;
+//  * the noise row of the fused epilogue is requested 3 steps ahead, BEFORE the DMAs of the row that completes the same
+//    output row, so the one wait per step covers it.  The request is inline asm on purpose: the compiler's waitcnt
+//    model merges control-flow paths conservatively and puts a near-zero vmcnt before every use of a loaded VGPR,
+//    which drains the ring (measured: no gain over path 1 with a compiler-visible load).
+// Taps are applied in the same order as path 1 (bit-identical results).  Measured on the headline blur
+// [256,1025,1025] -> [256,1024,1024] (tools/exp/blur_probe.hip, five boxes): fused 495-509 -> 404-434 us on the same box,
+// plain 408-432 -> 392-420 us; a linear copy of the same bytes takes 337-364 us on those boxes.
+struct DRParams {
+  const float* in0;   // position 0 of row 0 of plane 0 (= logical column -pad_x0), 16-byte aligned
+  float* out; const float* kern; const float* noise; const float* noise_weight; const float* bias;
+  int planes, channels, noise_batch, in_h, in_w, out_h, out_w, rs, pad_x0, pad_y0, kh, kw;
+  long long ps;
+  int th, strips, tiles_y; long long total_waves;
+  float alpha, act_scale;
+};
+
+template <int SIZE, int AUX, typename RSRC>   // AUX: cache policy bits of the load (gfx940+: 2 = nt, streaming)
+__device__ __forceinline__ void ufd_dma_to_lds(RSRC rsrc, float* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (a kernel template naming the builtin directly loses its host stub)
+  typedef __attribute__((address_space(3))) void* lds_void_ptr;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)lds, SIZE, voff, soff, 0, AUX);
+#endif
+}
+
+template <int N> __device__ __forceinline__ void ufd_wait_vm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; expcnt imm[6:4] and lgkmcnt imm[11:8] left at "no wait"
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+#endif
+}
+
+// VMEM operations issued after stage(k)'s two DMAs and before step k's wait.  Step s issues, in this order:
+// [noise request (EPI)] [2 DMAs of stage(s+3)] [wait] ... [store of output row s-3, s >= 3]; stages 0..2 come first.
+__host__ __device__ constexpr int ufd_ring_wait(int k, bool epi) {
+  int n = 0;
+  if (k >= 3) { if (k - 3 >= 3) ++n; }          // the store of the step that issued stage(k)
+  else n += 2 * (2 - k);                        // prologue stages k+1..2
+  for (int s = (k - 2 > 0 ? k - 2 : 0); s <= k; ++s) { n += 2 + (epi ? 1 : 0); if (s < k && s >= 3) ++n; }
+  return n;
+}
+
+template <bool EPI, bool NT, bool REMAP>
+__global__ __launch_bounds__(256) void ufd_dmaring_f32(const DRParams p) {
+  extern __shared__ __attribute__((aligned(16))) float ufd_ring[];
+  constexpr int SLOT = 320;   // floats per slot: 256 (64 lanes x 4) + 64 (the halo dwords; lanes >= 4 write zeros there)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lb = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const long long gw = (long long)lb * 4 + wv;
+  if (gw >= p.total_waves) return;  // wave-uniform
+  const int strip = (int)(gw % p.strips);
+  const long long t = gw / p.strips;
+  const int ty = (int)(t % p.tiles_y);
+  const long long plane = t / p.tiles_y;
+  float* ring = ufd_ring + wv * (4 * SLOT);
+
+  // flipped taps, zero-extended to 4x4 (wave-uniform -> SGPRs)
+  float kf[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+      kf[ky][kx] = (ky < p.kh && kx < p.kw) ? p.kern[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)] : 0.f;
+
+  const int c0 = (strip * 64 + lane) * 4;          // first output column = first window position of this lane
+  const unsigned PARK = 0xFFFFFFF0u;               // out of every buffer's range: the DMA writes zeros
+  const unsigned vmain = (c0 + 4 <= p.rs) ? (unsigned)c0 * 4u : PARK;
+  const int xe = (strip + 1) * 256 + lane;
+  const unsigned vext = (lane < 4 && xe < p.rs) ? (unsigned)xe * 4u : PARK;
+  unsigned mask = 0;                               // which of the 7 window positions are columns of the image
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int col = c0 + i - p.pad_x0;
+    mask |= (col >= 0 && col < p.in_w) ? 1u << i : 0u;
+  }
+  const bool lane_on = c0 < p.out_w;               // out_w % 4 == 0 (host)
+  const int oy0 = ty * p.th, oy_end = min(oy0 + p.th, p.out_h);
+  const bool full = oy0 + p.th <= p.out_h;         // wave-uniform: the static counts assume every step >= 3 stores
+  const int iy0 = oy0 - p.pad_y0;
+  const int nsteps = p.th + 3;
+  float* pin = const_cast<float*>(p.in0 + plane * p.ps);
+  float* pout = p.out + plane * (long long)p.out_h * p.out_w;
+
+  float nw = 0.f, bv = 0.f;
+  const float* nplane = nullptr;
+  if (EPI) {
+    const int ch = (int)(plane % p.channels), smp = (int)(plane / p.channels);
+    nw = p.noise_weight ? p.noise_weight[0] : 0.f;
+    bv = p.bias ? p.bias[ch] : 0.f;
+    nplane = p.noise + (p.noise_batch == 1 ? 0LL : (long long)smp * p.out_h * p.out_w);
+  }
+  const unsigned nvoff = lane_on ? (unsigned)c0 * 4u : 0u;
+  f32x4 nz[4];   // noise rows in flight (row k requested at step k, used at step k+3)
+  auto noise_req = [&](f32x4& dst, int row) {
+    const float* rowp = nplane + (long long)row * p.out_w;   // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(nvoff), "s"(rowp) : "memory");
+#else
+    (void)rowp; (void)nvoff; (void)dst;
+#endif
+  };
+  auto noise_ack = [&](f32x4& v) {   // after the wait that covers the request: from here on the value may be used
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v) : : "memory");
+#endif
+  };
+  auto issue = [&](int k, int slot) {
+    const int iy = iy0 + k;
+    const bool ok = k < nsteps && iy >= 0 && iy < p.in_h;   // wave-uniform; else: num_records 0 -> zeros
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(pin, 0, ok ? p.in_h * p.rs * 4 : 0, 0x00020000);
+    const unsigned soff = ok ? (unsigned)iy * (unsigned)p.rs * 4u : 0u;
+    ufd_dma_to_lds<16, NT ? 2 : 0>(rsrc, ring + slot * SLOT, vmain, soff);
+    ufd_dma_to_lds<4, NT ? 2 : 0>(rsrc, ring + slot * SLOT + 256, vext, soff);
+  };
+  float W[4][7];   // the 4-row window of this lane's 7 columns
+  auto take = [&](int slot, int wi) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ring + slot * SLOT + lane * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(ring + slot * SLOT + lane * 4 + 4);
+    const float x[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) W[wi][i] = (mask >> i) & 1 ? x[i] : 0.f;
+  };
+  auto emit = [&](int oy, int w0, int w1, int w2, int w3, const f32x4& nzv) {
+    if (oy >= oy_end) return;  // wave-uniform (partial tiles only)
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) v = fmaf(W[w0][e + kx], kf[0][kx], v);
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) v = fmaf(W[w1][e + kx], kf[1][kx], v);
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) v = fmaf(W[w2][e + kx], kf[2][kx], v);
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) v = fmaf(W[w3][e + kx], kf[3][kx], v);
+      acc[e] = v;
+    }
+    if constexpr (EPI) {
+      // same roundings as fmgan_noise_bias_act_f32: (y + nw*n) + b, select, *alpha, *scale — no FMA contraction
+      const float n[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = __fadd_rn(__fadd_rn(acc[e], __fmul_rn(nw, n[e])), bv);
+        acc[e] = __fmul_rn(v > 0.f ? v : __fmul_rn(v, p.alpha), p.act_scale);
+      }
+    }
+    const f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
+    if (lane_on) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(pout + (long long)oy * p.out_w + c0));
+  };
+
+#define UFD_STEP(K, J, NW)                                                                            \
+  {                                                                                                   \
+    if (EPI) noise_req(nz[(J) & 3], min(oy0 + (K), p.out_h - 1));                                     \
+    issue((K) + 3, ((J) + 3) & 3);                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (full) ufd_wait_vm<NW>(); else ufd_wait_vm<0>();                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (EPI && (K) >= 3) noise_ack(nz[((J) + 1) & 3]);                                                \
+    take((J) & 3, (J) & 3);                                                                           \
+    if ((K) >= 3) emit(oy0 + (K) - 3, ((J) + 1) & 3, ((J) + 2) & 3, ((J) + 3) & 3, (J) & 3, nz[((J) + 1) & 3]); \
+  }
+  issue(0, 0); issue(1, 1); issue(2, 2);
+  UFD_STEP(0, 0, ufd_ring_wait(0, EPI)) UFD_STEP(1, 1, ufd_ring_wait(1, EPI))
+  UFD_STEP(2, 2, ufd_ring_wait(2, EPI)) UFD_STEP(3, 3, ufd_ring_wait(3, EPI))
+  UFD_STEP(4, 0, ufd_ring_wait(4, EPI)) UFD_STEP(5, 1, ufd_ring_wait(5, EPI))
+  UFD_STEP(6, 2, ufd_ring_wait(6, EPI)) UFD_STEP(7, 3, ufd_ring_wait(7, EPI))
+  constexpr int NS = ufd_ring_wait(8, EPI);
+  for (int kb = 8; kb < nsteps; kb += 4) {
+    UFD_STEP(kb, 0, NS)
+    if (kb + 1 >= nsteps) break;
+    UFD_STEP(kb + 1, 1, NS)
+    if (kb + 2 >= nsteps) break;
+    UFD_STEP(kb + 2, 2, NS)
+    if (kb + 3 >= nsteps) break;
+    UFD_STEP(kb + 3, 3, NS)
+  }
+#undef UFD_STEP
+  ufd_wait_vm<0>();   // nothing of this wave's ring (or its noise requests) is in flight when it ends
+}
+
 // ---------------------------------------------------------------- path 2: plane-tile (f32, up=down=1, k<=4x4, small planes)
 // Planes of 4..65 px are too narrow for a wave-wide strip.  A block stages PB whole planes (contiguous in memory,
 // so the copy is one flat coalesced stream) in LDS and each thread filters consecutive outputs from there.
@@ -457,8 +652,67 @@ struct UfdEpilogue {
   int channels, noise_batch; float alpha, act_scale;
 };
 
+// Path 1b serves the aligned-row layout only: position 0 of every row (= logical column -pad_x0) on a 16-byte
+// boundary, row / plane pitch multiples of 4 floats, rows of the output 16-byte aligned, a noise plane when fused.
+// FMGAN_UFD_DMA=0 keeps path 1 (A/B measurements).
+bool dmaring_ok(const void* in, const void* out, const UfdParams& p, const UfdEpilogue* ep) {
+  const char* e = getenv("FMGAN_UFD_DMA");   // read per call: the tests switch it inside one process
+  if (e && e[0] == '0') return false;
+  const uintptr_t in0 = (uintptr_t)in - 4u * (unsigned)p.pad_x0;
+  if (p.pad_x0 < 0 || p.pad_x0 > 3 || (in0 & 15) || ((uintptr_t)out & 15)) return false;
+  if ((p.in_row_stride & 3) || (p.in_plane_stride & 3) || (p.out_w & 3) || p.out_w < 256 || p.out_h < 8) return false;
+  if (p.in_row_stride < p.in_w + p.pad_x0) return false;                       // the shifted row must fit its pitch
+  if ((long long)p.in_h * p.in_row_stride * 4 > 0x7fffffffLL) return false;    // num_records / soffset are 32-bit
+  if (ep && (!ep->noise || ((uintptr_t)ep->noise & 15))) return false;
+  return true;
+}
+
+int launch_dmaring(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s,
+                   const UfdEpilogue* ep) {
+  DRParams r{};
+  r.in0 = (const float*)in - p.pad_x0; r.out = (float*)out; r.kern = (const float*)kern;
+  if (ep) {
+    r.noise = ep->noise; r.noise_weight = ep->noise_weight; r.bias = ep->bias;
+    r.channels = ep->channels; r.noise_batch = ep->noise_batch; r.alpha = ep->alpha; r.act_scale = ep->act_scale;
+  }
+  r.planes = p.major; r.in_h = p.in_h; r.in_w = p.in_w; r.out_h = p.out_h; r.out_w = p.out_w;
+  r.rs = p.in_row_stride; r.ps = p.in_plane_stride; r.pad_x0 = p.pad_x0; r.pad_y0 = p.pad_y0; r.kh = p.kh; r.kw = p.kw;
+  r.strips = (p.out_w + 255) / 256;
+  // Largest row tile (halo re-read = 3/TH) that divides the height and still leaves >= 32 waves per CU in the grid.
+  const long long want = (long long)FMGAN_NUM_CU * 32;
+  int th = 64;
+  while (th > 8 && ((p.out_h % th) != 0 || (long long)p.major * r.strips * (p.out_h / th) < want)) th >>= 1;
+  r.th = th;
+  r.tiles_y = (p.out_h + th - 1) / th;
+  r.total_waves = (long long)p.major * r.strips * r.tiles_y;
+  const long long blocks = (r.total_waves + 3) / 4;
+  if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+  const dim3 g((unsigned)blocks), b(256);
+  const size_t lds = 4 * 4 * 320 * sizeof(float);   // 4 waves x 4 slots x (256 + 64) floats
+  // Block order and cache policy (experiment switch FMGAN_UFD_DMA = n: nt loads, x: XCD-contiguous order + nt loads).
+  // Default: hardware order, cached loads.  Blocks are dealt round-robin over the 8 XCDs, so with tiles numbered
+  // (strip, row tile, plane) an XCD sees the SAME few (strip, row tile) positions of every plane: its share of the
+  // noise plane is a few hundred KB that stays in its L2 for all planes, where the XCD-contiguous order of path 1
+  // re-fetches it per plane (FETCH_SIZE of the fused headline blur, standalone: 1.68x the input with XCD-contiguous
+  // order, 1.51x with nt loads on top, 1.12x in hardware order; plain blur 1.08x either way).
+  const char* e = getenv("FMGAN_UFD_DMA");
+  const char mode = e ? e[0] : '1';
+  if (mode == 'x') {
+    if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, true, true>), g, b, lds, s, r);
+    else hipLaunchKernelGGL((ufd_dmaring_f32<false, true, true>), g, b, lds, s, r);
+  } else if (mode == 'n') {
+    if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, true, false>), g, b, lds, s, r);
+    else hipLaunchKernelGGL((ufd_dmaring_f32<false, true, false>), g, b, lds, s, r);
+  } else {
+    if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, false, false>), g, b, lds, s, r);
+    else hipLaunchKernelGGL((ufd_dmaring_f32<false, false, false>), g, b, lds, s, r);
+  }
+  return fmgan_check_launch();
+}
+
 int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s,
                     const UfdEpilogue* ep = nullptr) {
+  if (dmaring_ok(in, out, p, ep)) return launch_dmaring(in, kern, out, p, s, ep);
   RMParams r{};
   if (ep) {
     r.fuse = 1; r.noise = ep->noise; r.noise_weight = ep->noise_weight; r.bias = ep->bias;

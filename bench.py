@@ -487,7 +487,7 @@ def main():
         if batch == wl['batch'] and args.workload == 'pairs1024':
             traffic, traffic_src = committed_traffic()
 
-        out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_rowmarch_f32<4> (blur + fused noise/bias/lrelu store) [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
+        out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_dmaring_f32<true> (blur + fused noise/bias/lrelu store, LDS-DMA row ring) [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                            'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': ms, 'launches': n,
                            'algorithmic_bytes': bytes_alg}

@@ -137,6 +137,47 @@ def test_blur_with_fused_epilogue_matches_two_passes(cfg):
     assert _native.blur_noise_bias_act(p0, dev(), b, c, 17, 17, ps, rs, k, (1, 1), None, None, None, 0.2, 1.0) is None
 
 
+@pytest.mark.parametrize('cfg', [
+    # (batch, channels, in_h, in_w, pad, taps, noise_batch)
+    (1, 2, 257, 257, (1, 1), 'blur4', 1),          # out 256 x 256: one strip
+    (2, 3, 101, 261, (1, 1), 'blur4', 2),          # out 260 wide (second strip nearly empty), 100 rows: partial last tile
+    (1, 2, 65, 512, (2, 1), ('rand', 4, 4, 7), 1), # pad0 = 2: two masked columns on the left; out 512 x 65
+    (1, 1, 40, 1027, (3, 2), ('rand', 3, 4, 9), 1),# 3-row kernel, pad0 = 3, out 1029 - not a multiple of 4 -> path 1 on both sides
+    (1, 2, 36, 1029, (3, 2), ('rand', 4, 3, 11), 1),  # out 1032 x 38, 3-column kernel
+    (2, 2, 1025, 1025, (1, 1), 'blur4', 1),        # the headline geometry, 4 planes
+])
+def test_dma_ring_blur_equals_register_row_march(cfg, monkeypatch):
+    """upfirdn2d.hip path 1b (LDS-DMA ring, hand-counted s_waitcnt) against path 1 (register staging) on the same
+    aligned-row buffer: bit-identical, plain and with the fused noise/bias/lrelu store; NaN padding must not leak."""
+    from op import _native
+    from oracle import c_oracle
+    b, c, h, w, pad, taps, nb = cfg
+    k = cases.make_fir(taps).to(dev())
+    kh, kw = k.shape
+    oh, ow = h + pad[0] + pad[1] - kh + 1, w + pad[0] + pad[1] - kw + 1
+    x = synth.tensor(f'dma/{cfg}/x', (b * c, h, w)).to(dev())
+    nz = synth.tensor(f'dma/{cfg}/n', (nb, 1, oh, ow)).to(dev())
+    nw = torch.tensor([-0.61], device=dev())
+    bias = synth.tensor(f'dma/{cfg}/b', (c,)).to(dev())
+    buf, p0, ps, rs = _native.aligned_rows_buffer(b, c, h, w, pad[0], dev())
+    buf.fill_(float('nan'))
+    off = pad[0] % 4
+    buf[:, :, off:off + w] = x
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('FMGAN_UFD_DMA', mode)
+        plain = _native.upfirdn2d_strided(p0, dev(), b * c, h, w, ps, rs, k, pad[0], pad[1], pad[0], pad[1])
+        fused = _native.blur_noise_bias_act(p0, dev(), b, c, h, w, ps, rs, k, pad, nz, nw, bias, 0.2, 2 ** 0.5)
+        res[mode] = (plain, fused)
+    assert res['0'][0].shape[-2:] == (oh, ow)
+    assert torch.equal(res['0'][0], res['1'][0])
+    assert res['0'][1] is not None and torch.equal(res['0'][1], res['1'][1])
+    assert not torch.isnan(res['1'][1]).any()
+    ref = c_oracle.upfirdn2d(x[:1].reshape(1, h, w, 1).cpu().numpy(), k.cpu().numpy(), (1, 1), (1, 1),
+                             (pad[0], pad[1], pad[0], pad[1]))
+    np.testing.assert_allclose(res['1'][0][:1].cpu().numpy().reshape(ref.shape), ref, **OP_TOL)
+
+
 def test_modconv_strided_output_matches_contiguous():
     from op import _native
     for (b, cin, cout, h, w) in ((2, 8, 40, 16, 16), (1, 16, 130, 9, 7), (9, 12, 20, 4, 4)):

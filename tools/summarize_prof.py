@@ -9,6 +9,12 @@ import sys
 from collections import defaultdict
 
 
+
+def headline(name):
+    """The headline blur's kernels: path 1b (aligned-row input: every in-step launch) and path 1 (bench.py's standalone
+    op on a contiguous tensor)."""
+    return 'ufd_rowmarch_f32<4' in name or 'ufd_dmaring_f32' in name
+
 def find(d, pat):
     return sorted(glob.glob(os.path.join(d, '**', pat), recursive=True))
 
@@ -45,7 +51,7 @@ def main(out):
             nm = r['Kernel_Name']
             if 'ufd_' in nm or 'modconv' in nm or 'fba_' in nm or 'torgb' in nm or 'noise_bias' in nm:
                 label = short(nm, 90)
-                if 'ufd_rowmarch_f32<4' in nm and r.get('Grid_Size_X') == '1048576':
+                if headline(nm) and r.get('Grid_Size_X') == '1048576':
                     # the headline blur: launches inside a step (fused epilogue) vs bench.py's back-to-back plain op
                     t = int(r['Start_Timestamp'])
                     in_step = last_headline is None or t - last_headline > 3_000_000
@@ -63,7 +69,7 @@ def main(out):
     # steady state: kernels between the last two launches of the headline blur = one full step
     for f in find(os.path.join(out, 'trace'), '*kernel_trace.csv'):
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-        marks = [i for i, r in enumerate(rows) if 'ufd_rowmarch_f32<4' in r['Kernel_Name']]
+        marks = [i for i, r in enumerate(rows) if headline(r['Kernel_Name'])]
         big = max((int(rows[i]['Grid_Size_X']) for i in marks), default=0)
         marks = [i for i in marks if int(rows[i]['Grid_Size_X']) == big]
         # bench.py also launches the headline blur back to back (standalone roofline): a step is a pair of marks
@@ -112,7 +118,7 @@ def headline_traffic(out, tag):
     for sub, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         for f in find(os.path.join(out, sub), '*counter_collection.csv'):
             vals = sorted((int(r['Dispatch_Id']), float(r['Counter_Value'])) for r in csv.DictReader(open(f))
-                          if r['Counter_Name'] == ctr and 'ufd_rowmarch_f32<4' in r['Kernel_Name'] and r['Grid_Size'] == '1048576')
+                          if r['Counter_Name'] == ctr and headline(r['Kernel_Name']) and r['Grid_Size'] == '1048576')
             insitu = [v for i, (d, v) in enumerate(vals)
                       if (i == 0 or d - vals[i - 1][0] > 50) and (i + 1 == len(vals) or vals[i + 1][0] - d > 50)]
             alone = [v for d, v in vals if v not in insitu]
@@ -124,7 +130,7 @@ def headline_traffic(out, tag):
     fi, fa = res['FETCH_SIZE']
     wi, wa = res['WRITE_SIZE']
     doc = {
-        'kernel': 'ufd_rowmarch_f32<4,true> [256,1025,1025]->[256,1024,1024] (grid 1048576 threads)',
+        'kernel': 'ufd_dmaring_f32<true> in a step / ufd_rowmarch_f32<4,true> standalone, [256,1025,1025]->[256,1024,1024] (grid 1048576 threads)',
         'correction': 'gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact',
         'in_step': {'what': 'blur + fused noise/bias/lrelu store, aligned-row strided input (as launched by StyledConv)',
                     'FETCH_SIZE_KiB_per_launch': sum(fi) / len(fi), 'WRITE_SIZE_KiB_per_launch': sum(wi) / len(wi),
