@@ -380,7 +380,9 @@ def test_world2_phases_equal_single_process(mode, tmp_path):
                 np.testing.assert_array_equal(r0[key + '/s'], r1[key + '/s'])       # ranks agree bit for bit
                 scale = float(np.abs(s).max())
                 diff = np.abs(r0[key + '/s'] - s)
-                bad = diff > 2e-3 * scale + 1e-5 * net_scale
+                # encoder tensors: MIOpen's fp32 wgrad / double-backward kernels are not reproducible run to run and put
+                # isolated elements up to 6e-3 of the tensor's max apart (same measurement as FLOOR_MIOPEN)
+                bad = diff > (1e-2 if k.startswith('e_') else 2e-3) * scale + 1e-5 * net_scale
                 # The losses have kinks (|x| of the L1 term, the leaky ReLUs): a pixel that sits on one flips the side it
                 # takes with the last bit of the forward, and the gradient of a few weights jumps by a discrete amount —
                 # the reference's own fp32 and fp64 runs disagree on exactly such elements (g/e_wp/styles.3.convs.0.weight,
