@@ -27,6 +27,18 @@ from Util.streams import overlap_ok, run_deferred, side_streams
 # forward_deferred — the synthesis network.  2 streams measured best (more streams than hardware queues serialise
 # behind each other: 4 streams 325, 3 streams 331-340, 2 streams 337-340 pairs/s).
 HEAD_STREAMS = int(os.environ.get('FMGAN_PSP_STREAMS', '2'))
+# Optional (FMGAN_PSP_GROUPED=1): the heads of one pyramid level (3 coarse, 4 middle, up to 11 fine) have the same
+# structure and, after their first conv, the same shapes — their tails can run as ONE chain of grouped convs (groups =
+# heads of the level) after one wide first conv (Cout = heads*512) on the level's shared feature map; 98 convs + 98
+# bias/LeakyReLU launches become 15 + 15, with the heads' parameters re-pointed once at slices of one buffer per
+# (level, depth) (_flatten_heads) so that the wide weight IS the live parameters.  Measured (MI355X, B=8, MIOpen fp32,
+# tools/exp_grouped_heads.py): standalone the 11 fine heads' tails drop from 2.28 to 1.54 ms (8^2->4^2 0.312 -> 0.139,
+# 4^2->2^2 0.318 -> 0.062, 2^2->1^2 0.297 -> 0.054: launch-latency-bound when separate; the 64^2->32^2 first convs run at
+# 133 TFLOP/s either way) — but IN A STEP the grouped form is 2-3 % SLOWER (pairs1024 348 -> 340 pairs/s, pairs256
+# 583 -> 574): the per-head tails were already hidden under the synthesis network by the two head streams, whereas the
+# wide convs compete with its MFMA kernels for every CU and hold back all latents of a level until its last head is
+# done.  The per-head form therefore stays the default.
+GROUP_HEADS = os.environ.get('FMGAN_PSP_GROUPED', '0') == '1'
 
 _TAPS = {18: (3, 5, 7), 50: (6, 20, 23)}   # units whose outputs feed the pyramid (psp_encoders.py:105-108)
 
@@ -82,6 +94,7 @@ class GradualStyleEncoder(Module):
         self.channels_last = True     # GPU only; set False to keep NCHW activations
         self._cl_key = None
         self._live_weights = None
+        self._flat = None             # per level: (head indices, [(wide weight, wide bias) per depth])
 
     def _to_channels_last(self):
         """Re-lay the conv weights as NHWC once per (device, parameter storage); values and shapes are untouched."""
@@ -92,6 +105,68 @@ class GradualStyleEncoder(Module):
                 if isinstance(m, nn.Conv2d):
                     m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
             self._cl_key = (w.device, self.input_layer[0].weight.data_ptr())
+
+    def _levels(self):
+        n = self.style_count
+        return [list(range(0, min(self.coarse_ind, n))), list(range(self.coarse_ind, min(self.middle_ind, n))),
+                list(range(self.middle_ind, n))]
+
+    def _flatten_heads(self):
+        """One buffer per (pyramid level, conv depth) holding the heads' conv weights back to back ([G*512,512,3,3] in the
+        current memory format) and one for the biases; every head's parameter is re-pointed at its slice, so the wide
+        tensors are the live parameters themselves (optimizer steps, EMA `.data` updates and `load_state_dict` copies
+        write through).  Re-pointing a parameter elsewhere (`p.data = ...`) is detected by address and flattens again."""
+        def aliased(big, parts):
+            step = big[0:parts[0].shape[0]].numel() * big.element_size()
+            return all(q.data_ptr() == big.data_ptr() + g * step and q.stride() == big[0:q.shape[0]].stride()
+                       for g, q in enumerate(parts))
+        if self._flat is not None and all(aliased(wb, [self.styles[j].convs[2 * d].weight for j in idxs]) and
+                                          aliased(bb, [self.styles[j].convs[2 * d].bias for j in idxs])
+                                          for idxs, per_depth in self._flat for d, (wb, bb) in enumerate(per_depth)):
+            return self._flat
+        flat = []
+        with torch.no_grad():
+            for idxs in self._levels():
+                if not idxs:
+                    continue
+                per_depth = []
+                for d in range(len(self.styles[idxs[0]].convs) // 2):
+                    convs = [self.styles[j].convs[2 * d] for j in idxs]
+                    wb = torch.cat([c.weight.data for c in convs], 0)
+                    if convs[0].weight.data.is_contiguous(memory_format=torch.channels_last) and wb.dim() == 4:
+                        wb = wb.contiguous(memory_format=torch.channels_last)
+                    bb = torch.cat([c.bias.data for c in convs], 0)
+                    co = convs[0].weight.shape[0]
+                    for g, c in enumerate(convs):
+                        c.weight.data = wb[g * co:(g + 1) * co]
+                        c.bias.data = bb[g * co:(g + 1) * co]
+                    per_depth.append((wb, bb))
+                flat.append((idxs, per_depth))
+        self._flat = flat
+        return flat
+
+    def _grouped_heads(self, level, feat):
+        """All heads of one pyramid level as one chain: wide first conv on the shared feature map, grouped convs after it,
+        bias + LeakyReLU on the HIP fused_bias_act kernel, the EqualLinears as one batched matmul.  Returns the level's
+        latents [B,512] in head order."""
+        idxs, per_depth = level
+        G = len(idxs)
+        blocks = [self.styles[j] for j in idxs]
+        x = feat
+        for d, (wb, bb) in enumerate(per_depth):
+            conv, act = blocks[0].convs[2 * d], blocks[0].convs[2 * d + 1]
+            y = F.conv2d(x, wb, None, conv.stride, conv.padding, 1, 1 if d == 0 else G)
+            n, c, h, w = y.shape
+            if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
+                y = fused_leaky_relu(y.permute(0, 2, 3, 1).reshape(-1, c), bb, act.negative_slope, 1.0)
+                x = y.view(n, h, w, c).permute(0, 3, 1, 2)
+            else:
+                x = fused_leaky_relu(y, bb, act.negative_slope, 1.0)
+        out_c = blocks[0].out_c
+        xs = x.reshape(-1, G, out_c).transpose(0, 1)                          # [G, B, 512]
+        ws, bs = zip(*[b.linear._scaled_params() for b in blocks])
+        out = torch.baddbmm(torch.stack(bs, 0).unsqueeze(1), xs, torch.stack(ws, 0).transpose(1, 2))
+        return tuple(out.unbind(0))
 
     def _upsample_add(self, x, y):
         """Bilinear (align_corners) resize of x to y's size, plus y (psp_encoders.py:82-98)."""
@@ -128,6 +203,25 @@ class GradualStyleEncoder(Module):
             if i in (t1, t2, t3):
                 feats[i] = x
         c1, c2, c3 = feats[t1], feats[t2], feats[t3]
+        if GROUP_HEADS and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+            flat = self._flatten_heads()
+            if HEAD_STREAMS > 1 and overlap_ok(x):
+                streams = side_streams(x.device, HEAD_STREAMS, 'psp-heads')
+
+                def level(k, feat):
+                    wait, outs = run_deferred(streams[k % HEAD_STREAMS], self._grouped_heads, flat[k], feat)
+                    return [(wait, o) for o in outs]
+            else:
+                def level(k, feat):
+                    return [((lambda: None), o) for o in self._grouped_heads(flat[k], feat)]
+            latents = level(0, c3)
+            if len(flat) > 1:
+                p2 = self._upsample_add(c3, self.latlayer1(c2))
+                latents += level(1, p2)
+            if len(flat) > 2:
+                p1 = self._upsample_add(p2, self.latlayer2(c1))
+                latents += level(2, p1)
+            return latents
         if HEAD_STREAMS > 1 and overlap_ok(x):
             streams = side_streams(x.device, HEAD_STREAMS, 'psp-heads')
 

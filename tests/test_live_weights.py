@@ -163,3 +163,46 @@ def test_psp_heads_see_data_mutation():
         b = e(p)
     np.testing.assert_allclose(b[:, :2].cpu().numpy(), a[:, :2].cpu().numpy(), atol=1e-4 * float(a.abs().max()))
     assert float((b[:, 2] - a[:, 2]).abs().max()) > 1e-3 * float(a[:, 2].abs().max())
+
+
+@pytest.mark.gpu
+def test_psp_grouped_heads_equal_per_head_form_and_track_the_live_parameters(monkeypatch):
+    """GradualStyleEncoder's inference path runs the heads of a pyramid level as one chain of wide / grouped convs over
+    parameters re-pointed at slices of one buffer (psp_encoders._flatten_heads).  Same values as the per-head form
+    (MIOpen picks other kernels: rounding-level differences only), and the wide weights ARE the parameters: in-place
+    updates, load_state_dict and re-pointed `.data` are all seen by the next forward."""
+    import types
+    from psp_encoder_model.encoders import psp_encoders
+    e = psp_encoders.GradualStyleEncoder(18, 'ir_se', types.SimpleNamespace(input_nc=3, n_styles=10))
+    sd = synth.state_dict('psp', e.state_dict(), seed=7)
+    e.load_state_dict(sd)
+    e = e.to(dev()).eval()
+    p = synth.tensor('gh/photo', (2, 3, 256, 256), dist='uniform').to(dev())
+    with torch.no_grad():
+        monkeypatch.setattr(psp_encoders, 'GROUP_HEADS', False)
+        ref = e(p).clone()
+        monkeypatch.setattr(psp_encoders, 'GROUP_HEADS', True)
+        a = e(p).clone()
+        scale = float(ref.abs().max())
+        assert float((a - ref).abs().max()) <= 5e-6 * scale
+        assert e._flat is not None and [len(idx) for idx, _ in e._flat] == [3, 4, 3]
+        # the parameters are views of the wide buffers
+        wide = e._flat[2][1][0][0]
+        assert e.styles[8].convs[0].weight.data_ptr() == wide.data_ptr() + wide[0:512].numel() * 4
+        # in-place update of ONE head's conv weight (optimizer step / EMA accumulate): only that head's latent moves
+        e.styles[8].convs[2].weight.data.mul_(0.5)
+        b = e(p).clone()
+        assert float((b[:, 8] - a[:, 8]).abs().max()) > 1e-3 * float(a[:, 8].abs().max())
+        keep = [j for j in range(10) if j != 8]
+        assert float((b[:, keep] - a[:, keep]).abs().max()) <= 5e-6 * scale
+        # load_state_dict copies in place: back to the first result
+        e.load_state_dict({k: v.to(dev()) for k, v in sd.items()})
+        assert float((e(p) - a).abs().max()) <= 5e-6 * scale
+        # a parameter re-pointed elsewhere is noticed (flattened again) instead of silently ignored
+        e.styles[1].convs[0].bias.data = e.styles[1].convs[0].bias.data.clone() + 1.0
+        c = e(p).clone()
+        assert float((c[:, 1] - a[:, 1]).abs().max()) > 1e-3 * float(a[:, 1].abs().max())
+        assert e.styles[1].convs[0].bias.data_ptr() == e._flat[0][1][0][1].data_ptr() + 512 * 4
+        # the per-head form on the flattened parameters gives the same thing
+        monkeypatch.setattr(psp_encoders, 'GROUP_HEADS', False)
+        assert float((e(p) - c).abs().max()) <= 5e-6 * scale
