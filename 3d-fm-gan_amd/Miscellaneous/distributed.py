@@ -27,8 +27,10 @@ def _active():
     return dist.is_available() and dist.is_initialized()
 
 
-def init_distributed(backend=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun). Returns (rank, world, device)."""
+def init_distributed(backend=None, force=False):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun). Returns (rank, world, device).
+    force: build the process group also for a job of one rank (a one-GPU box can then exercise the RCCL communicator,
+    its collectives and DDP: tests/test_hip_train.py::test_rccl_group_of_one)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -39,7 +41,7 @@ def init_distributed(backend=None):
     device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not _active():
+    if (world > 1 or force) and not _active():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = backend or ('nccl' if use_gpu else 'gloo')
@@ -206,7 +208,7 @@ class Replica(nn.Module):
         return self.module(*args, **kwargs)
 
 
-def data_parallel(module, device=None, overlap=True, find_unused_parameters=True):
+def data_parallel(module, device=None, overlap=True, find_unused_parameters=True, single_rank_ddp=False):
     """DataParallel replacement: DDP (bucketed RCCL all-reduce overlapped with backward) when a process group is up
     and the module has trainable parameters, else a plain Replica.  find_unused_parameters defaults to True because
     the 3-encoder scheme leaves the Generator's mapping network and constant input unused (input_is_latent=True,
@@ -218,7 +220,8 @@ def data_parallel(module, device=None, overlap=True, find_unused_parameters=True
     relayout = getattr(module, '_to_channels_last', None)
     if relayout is not None and getattr(module, 'channels_last', False) and next(module.parameters()).is_cuda:
         relayout()
-    if _active() and get_world_size() > 1 and overlap and any(p.requires_grad for p in module.parameters()):
+    if (_active() and (get_world_size() > 1 or single_rank_ddp) and overlap and
+            any(p.requires_grad for p in module.parameters())):
         ids = [device.index] if (device is not None and device.type == 'cuda') else None
         # broadcast_buffers=False: the only buffers are the encoders' BatchNorm statistics (eval mode, never updated,
         # SURVEY F13), the fixed noise maps and FIR taps — identical on every rank by construction

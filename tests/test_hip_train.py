@@ -408,3 +408,91 @@ class _PerHalfD(torch.nn.Module):
     def forward(self, x):
         h = x.shape[0] // 2
         return torch.cat([self.module(x[:h]), self.module(x[h:])], 0)
+
+
+_RCCL_WORKER = r'''
+import os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, '3d-fm-gan_amd'), os.path.join(root, 'tests')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import torch.distributed as dist
+import cases, synth
+from Miscellaneous import distributed as D
+import test_hip_train as H
+import train_3_encoder as T
+rank, world, device = D.init_distributed(backend='nccl', force=True)
+assert (rank, world) == (0, 1) and dist.get_backend() == 'nccl' and device.type == 'cuda'
+# every collective the training path and bench.py use, on the RCCL communicator
+x = torch.arange(1024, dtype=torch.float32, device=device)
+for alg in D.GRAD_ALGORITHMS:
+    f = x.clone(); D._reduce_flat(f, 1, alg); assert torch.equal(f, x), alg
+m = torch.tensor([3, 0, 1], dtype=torch.int32, device=device); dist.all_reduce(m, op=dist.ReduceOp.MAX)
+assert m.tolist() == [3, 0, 1]
+t = torch.tensor([1.5], dtype=torch.float64, device=device); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert t.item() == 1.5
+v = torch.tensor([2.0], device=device, requires_grad=True)
+g, = torch.autograd.grad(T._global_mean(v * 3.0), v); assert g.item() == 3.0
+from torch.distributed.nn import functional as dist_fn      # what _global_mean uses when world > 1
+y = dist_fn.all_reduce(v * 3.0); g, = torch.autograd.grad(y.sum(), v); assert y.item() == 6.0 and g.item() == 3.0
+assert D.reduce_sum(x).equal(x) and D.all_gather({'a': 1}) == [{'a': 1}]
+dist.barrier()
+# the training iteration with its networks inside DistributedDataParallel over RCCL (bucket views, NHWC pSp weights)
+c = cases.TRAIN_STEP_CASE
+nets = H.build_nets(c['size'], with_d=True, n_mlp=2)
+for n_ in nets.values():
+    n_.requires_grad_(True)
+wrapped = {k: D.data_parallel(n_, device, single_rank_ddp=True) for k, n_ in nets.items()}
+assert all(isinstance(w, torch.nn.parallel.DistributedDataParallel) for w in wrapped.values())
+photo, render, ref, probe = H.train_inputs()
+res = {}
+for phase in ('d', 'r1', 'g', 'ppl'):
+    for n_ in nets.values():
+        n_.zero_grad(set_to_none=True)
+    H.run_phase(phase, wrapped, H.train_args(grad_sync='ddp'), photo, render, ref, probe, c['ppl_idx'])
+    for k, n_ in nets.items():
+        for name, p in n_.named_parameters():
+            if p.grad is not None:
+                assert torch.isfinite(p.grad).all(), (phase, k, name)
+                res[f'{phase}/{k}/{name}'] = cases.grad_sample(p.grad)[0]
+np.savez(sys.argv[2], **res)
+D.synchronize()
+dist.destroy_process_group()
+print('rccl-ok')
+'''
+
+
+@pytest.mark.timeout(900)
+def test_rccl_group_of_one(tmp_path):
+    """`backend="nccl"` (= RCCL) has to come up on this box: a process group of ONE rank is enough to load RCCL, build a
+    communicator on the GPU, run every collective the path uses (all_reduce SUM/MAX in f32/f64/i32, reduce_scatter +
+    all_gather, all_to_all, the differentiable all-reduce, barrier, object gather) and drive the four training phases
+    through DistributedDataParallel with gradient-as-bucket-view on the NHWC pSp weights.  The gradients must equal the
+    no-process-group run of the same phases (a group of one averages nothing).  Multi-rank arithmetic is covered by the
+    gloo tests; what only RCCL can show on one GPU is that this branch works at all."""
+    import subprocess
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(_RCCL_WORKER)
+    out = str(tmp_path / 'rccl.npz')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(29900 + os.getpid() % 90), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    proc = subprocess.run([sys.executable, str(script), ROOT, out], env=env, capture_output=True, text=True, timeout=800)
+    assert proc.returncode == 0 and 'rccl-ok' in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
+    r = np.load(out)
+    c = cases.TRAIN_STEP_CASE
+    nets = build_nets(c['size'], with_d=True, n_mlp=2)
+    photo, render, ref, probe = train_inputs()
+    checked = 0
+    for phase in ('d', 'r1', 'g', 'ppl'):
+        for m in nets.values():
+            m.zero_grad(set_to_none=True)
+        run_phase(phase, nets, train_args(), photo, render, ref, probe, c['ppl_idx'])
+        for k, m in nets.items():
+            grads = [(n, p.grad) for n, p in m.named_parameters() if p.grad is not None]
+            net_scale = max([float(g.abs().max()) for _, g in grads] + [0.0])
+            for name, gr in grads:
+                s, _ = cases.grad_sample(gr)
+                d = np.abs(r[f'{phase}/{k}/{name}'] - s)
+                tol = (1e-2 if k.startswith('e_') else 2e-3) * float(np.abs(s).max()) + 1e-5 * net_scale
+                assert (d > tol).sum() <= 1 and d.max() <= 0.1 * float(np.abs(s).max()) + 1e-5 * net_scale, (phase, k, name)
+                checked += 1
+    assert checked > 600
