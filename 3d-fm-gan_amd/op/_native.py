@@ -44,6 +44,8 @@ def lib():
     _sig(L.fmgan_blur_noise_bias_act_f32, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6 + [vp] * 3 + [i, f, f, vp])
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
+    _sig(L.fmgan_prelu_backward_blocks, [ll, i])
+    _sig(L.fmgan_prelu_backward_f32, [vp] * 5 + [ll, i, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_wsq_f32, [vp] * 2 + [i] * 3 + [vp])
     _sig(L.fmgan_modconv_demod_wsq_f32, [vp] * 3 + [i] * 3 + [f, f, vp])
@@ -241,6 +243,24 @@ def noise_bias_act(x, noise, noise_weight, bias, alpha, scale):
                                              float(alpha), float(scale), stream), 'noise_bias_act')
         _observer.end(tok)
     return out
+
+
+def prelu_backward(x, grad, slope):
+    """Backward of PReLU on channels-innermost data: x, grad [rows, C] f32 contiguous, slope [C] ->
+    (grad_x [rows, C], grad_slope [C]).  Returns None when the kernel does not serve the shape (C % 4 != 0)."""
+    require_gpu(x, 'input')
+    rows, c = x.shape
+    if c % 4 != 0 or rows == 0:
+        return None
+    blocks = lib().fmgan_prelu_backward_blocks(rows, c)
+    gx = torch.empty_like(x)
+    partial = torch.empty((blocks, c), dtype=torch.float32, device=x.device)
+    with on_device(x) as stream:
+        st = lib().fmgan_prelu_backward_f32(ptr(x), ptr(grad), ptr(slope), ptr(gx), ptr(partial), rows, c, stream)
+    if st == -2:
+        return None
+    check(st, 'prelu_backward')
+    return gx, partial.sum(0)
 
 
 def modconv_demod(weight, style, scale, eps=1e-8, wsq=None):

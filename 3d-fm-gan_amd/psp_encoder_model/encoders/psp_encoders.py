@@ -13,9 +13,9 @@ import os
 import torch
 import torch.nn.functional as F
 from torch import nn
-from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
+from torch.nn import BatchNorm2d, Conv2d, Module, Sequential
 
-from .helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
+from .helpers import PReLU, bottleneck_IR, bottleneck_IR_SE, get_blocks
 from stylegan2 import EqualLinear
 from op import fused_leaky_relu
 from op.live_weights import LiveWeights

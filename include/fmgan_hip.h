@@ -142,6 +142,17 @@ int fmgan_noise_bias_act_f32(const float *x, const float *noise, const float *no
                              float alpha, float scale, void *stream);
 
 /*
+ * Backward of PReLU(channels) on channels-innermost activations (the pSp encoder's units,
+ * psp_encoder_model/encoders/helpers.py:107,130, run in NHWC): x/grad/grad_x [rows, channels] f32, slope [channels],
+ *   grad_x = grad * (x > 0 ? 1 : slope[c]);   partial[blk, c] = sum over the block's rows of grad * x * (x <= 0)
+ * partial [fmgan_prelu_backward_blocks(rows, channels), channels]: the caller sums it over dim 0 (deterministic).
+ * channels % 4 == 0 and 16-byte aligned pointers, else FMGAN_EUNSUPPORTED.
+ */
+int fmgan_prelu_backward_blocks(long long rows, int channels);
+int fmgan_prelu_backward_f32(const float *x, const float *grad, const float *slope, float *grad_x,
+                             float *partial, long long rows, int channels, void *stream);
+
+/*
  * Demodulation coefficients of ModulatedConv2d (stylegan2.py:258-262):
  *   demod[b,o] = rsqrt( sum_{i,k} (scale * weight[o,i,k] * style[b,i])^2 + eps )
  *   weight [cout, cin, ktaps] f32 (the [1,cout,cin,k,k] parameter), style [batch, cin] f32,

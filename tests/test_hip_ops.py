@@ -417,3 +417,33 @@ def test_upfirdn2d_random_arguments_vs_c_oracle():
         np.testing.assert_allclose(y.cpu().numpy(), ref, atol=tol * max(1.0, float(np.abs(ref).max())), rtol=tol,
                                    err_msg=f'{(major, h, w, minor)} k{kh}x{kw} up{(ux, uy)} down{(dx, dy)} pad{pads}')
         done += 1
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 33, 17), (3, 128, 8, 8), (1, 512, 5, 7), (4, 96, 16, 16), (2, 6, 9, 9)])
+def test_prelu_backward_kernel_vs_float64_autograd(shape):
+    """helpers.PReLU: the HIP backward (fmgan_prelu_backward_f32: grad_x in one pass, slope gradient from per-block partial
+    sums) against float64 autograd of nn.PReLU; C = 6 is not served by the kernel and must fall back to aten."""
+    from psp_encoder_model.encoders.helpers import PReLU
+    n, c, h, w = shape
+    x = synth.tensor(f'prelu/{shape}/x', shape).to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    g = synth.tensor(f'prelu/{shape}/g', shape).to(dev()).contiguous(memory_format=torch.channels_last)
+    a = synth.tensor(f'prelu/{shape}/a', (c,), scale=0.3).to(dev())
+    m = PReLU(c).to(dev())
+    m.weight.data.copy_(a)
+    y = m(x)
+    y.backward(g)
+    ref = torch.nn.PReLU(c).double()
+    ref.weight.data.copy_(a.double().cpu())
+    x64 = x.detach().double().cpu().contiguous().requires_grad_(True)
+    y64 = ref(x64)
+    y64.backward(g.double().cpu().contiguous())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y64.detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.numpy(), rtol=1e-6, atol=1e-7)
+    gw64 = ref.weight.grad.numpy()
+    np.testing.assert_allclose(m.weight.grad.cpu().numpy(), gw64, rtol=2e-5, atol=2e-6 * float(np.abs(gw64).max()) + 1e-6)
+    # create_graph=True takes the differentiable torch formulas: same first-order values, and a second derivative exists
+    x2 = x.detach().clone().requires_grad_(True)
+    gx, = torch.autograd.grad(m(x2), x2, g, create_graph=True)
+    np.testing.assert_allclose(gx.detach().cpu().numpy(), x64.grad.numpy(), rtol=1e-6, atol=1e-7)
+    gg, = torch.autograd.grad(gx.sum(), m.weight)
+    assert torch.isfinite(gg).all()
