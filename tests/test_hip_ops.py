@@ -264,7 +264,7 @@ def test_fused_act_golden(c, golden):
 
 
 @pytest.mark.parametrize('act,grad', [(3, 0), (3, 1), (3, 2), (1, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize('shape', [(2, 6, 8, 8), (3, 5, 7, 3), (2, 32, 64, 64), (4, 512), (1, 3, 1, 1)])
+@pytest.mark.parametrize('shape', [(2, 6, 8, 8), (3, 5, 7, 3), (2, 32, 64, 64), (4, 512), (1, 3, 1, 1), (1031, 128)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64, torch.float16])
 def test_fused_bias_act_all_modes_vs_c_oracle(act, grad, shape, dtype):
     """Every act*10+grad code of the reference kernel (op/fused_bias_act_kernel.cu:36-45), a non-default alpha
