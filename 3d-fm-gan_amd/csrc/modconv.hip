@@ -19,6 +19,7 @@
 //     parity and both column parities so each lane stores the two adjacent columns as one 8-byte store.
 //   * Tiny layers (4x4 .. 8x8) pack several samples into one pixel tile.
 // Demodulation: one wave per output channel, sum over Cin by wave-shuffle butterfly.
+#include <type_traits>
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   float* Ws = smem;                 // [KC][9][BM]
   float* Xs = smem + KC * 9 * BM;   // [nb][KC][PH][PWP]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave index as an SGPR: LDS-DMA destinations (M0), piece guards and tile offsets derived from it stay scalar
+  // (left in a VGPR, every `buffer_load ... lds` sat in a waterfall loop with v_readfirstlane)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, khalf = lane >> 5;
   unsigned long long clk0 = 0, rt0 = 0;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
         for (int g = 0; g < RNP; ++g) o.b[j][g] *= o.s[g];
     }
   };
-  auto mma = [&](const Ops& o) {
+  auto mma = [&](const Ops& o, auto all_taps) {
     if constexpr (MODE != 1) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       // blocks skip those MFMAs (a wave-uniform bit per tap: same sums, bit for bit) and finish three times sooner.
 #pragma unroll
       for (int q = 0; q < 9; ++q)
-        if (tapmask & (1u << T[q][0]))
+        if (decltype(all_taps)::value || (tapmask & (1u << T[q][0])))
 #pragma unroll
           for (int m = 0; m < RM; ++m)
 #pragma unroll
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // (hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) in front of each group of four:
   // the sched_barriers keep "issue all reads of stage st+1, then run stage st's MFMAs" as written.)
   // hook(st): extra issue work placed in front of stage st's MFMAs (PIPE 1: a slice of the next chunk's DMA pieces)
-  auto contract = [&](auto&& hook) {
+  auto contract = [&](auto&& hook, auto all_taps) {
     Ops cur, nxt;
     fetch(cur, 0);
 #pragma unroll
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       }
       __builtin_amdgcn_sched_barrier(0);
       modulate(cur);
-      mma(cur);
+      mma(cur, all_taps);
       __builtin_amdgcn_sched_barrier(0);
       if (st + 1 < NSTAGE) cur = nxt;
     }
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       if (!(p.debug & 2)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       if (live && i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
-      contract([](int) {});
+      contract([](int) {}, std::false_type{});
     }
   } else {
     constexpr unsigned PARKED = 0xFFFFFFF0u;
@@ -621,9 +624,53 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       }
     };
 
-    if (i_begin < i_end) stage(i_begin, 0);
+    // Lean K loop for the common case — every chunk complete and DMA-servable, the patch and the style slice within the
+    // main tile's piece budget, all nine taps live, no debug switches: the general loop below re-tests all of that per
+    // chunk and per stage (spread / dma_ok / debug bits, the larger-than-main-tile piece loops with their div/mod
+    // address maths, one wave-uniform branch per tap in MODE 1), ~1300 scalar and vector instructions around the 60-72
+    // MFMAs of a chunk on the small tiles.  Same DMA pieces, same MFMA order: identical bits.
+    // (FMGAN_MC_DEBUG bit 3 forces the general loop: A/B measurements.)
+    const bool lean = fastc && p.debug == 0 && i_begin < i_end && ((i_end - i_begin) % KC) == 0 && x_pieces <= 4 * NUP &&
+                      s_pieces <= 4 && tapmask == 0x1FFu;
+    if (lean) {
+      auto piece = [&](int k, int i0, int bufi) {
+        float* Wb = smem + bufi * bstride;
+        float* Xb = Wb + WSZ;
+        if (k < NWP) {
+          if (WPIECES % 4 == 0 || 4 * k + wave < WPIECES)
+            dma_to_lds<16>(rsrc_w, Wb + (4 * k + wave) * 256, wvo[k < NWP ? k : 0], (unsigned)(i0 * 9 * p.cout * 4));
+        } else if (k < NWP + NUP) {
+          const int u = k - NWP;
+          if (4 * u + wave < x_pieces)
+            dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], (unsigned)(i0 * hw * 4));
+        } else if (wave < s_pieces) {
+          dma_to_lds<4>(rsrc_s, Xb + p.lds_patch_floats + wave * 64, svo, (unsigned)(i0 * 4));
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < NPC; ++k) piece(k, i_begin, 0);
+      int bufl = 0;
+      for (int i0 = i_begin; i0 < i_end; i0 += KC, bufl ^= 1) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int i1 = i0 + KC;
+        const bool more = i1 < i_end;
+        Wc = smem + bufl * bstride;
+        Xc = Wc + WSZ;
+        Sc = Xc + p.lds_patch_floats;
+        contract([&](int st) {
+          if (more) {
+#pragma unroll
+            for (int q = 0; q < PER_STAGE; ++q)
+              if (st * PER_STAGE + q < NPC) piece(st * PER_STAGE + q, i1, bufl ^ 1);
+          }
+        }, std::true_type{});
+      }
+    }
+    if (!lean && i_begin < i_end) stage(i_begin, 0);
     int buf = 0;
-    for (int i0 = i_begin; i0 < i_end; i0 += KC, buf ^= 1) {
+    for (int i0 = lean ? i_end : i_begin; i0 < i_end; i0 += KC, buf ^= 1) {
       // this wave's DMA pieces / LDS stores of chunk i0 have landed; after the barrier everyone's have, and every wave
       // has finished reading the other buffer (its ds_reads were retired before the MFMAs that consumed them)
       __builtin_amdgcn_s_waitcnt(0);
@@ -645,7 +692,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
           for (int q = 0; q < PER_STAGE; ++q)
             if (st * PER_STAGE + q < NPC) dma_piece(st * PER_STAGE + q, i1, buf ^ 1);
         }
-      });
+      }, std::false_type{});
     }
   }
 
@@ -907,8 +954,8 @@ inline char mc_variant(int mode, int cfg) {
   static bool init = false;
   if (!init) {
     // measured on MI355X (profiles/r02_modconv_variants.md): plain conv, Cout >= 96: 128 x 256 tile by LDS-DMA (C);
-    // Cout >= 48: 64 x 256 (C); Cout < 48: register pipeline; transposed conv, Cout >= 48: LDS-DMA (B)
-    const char defaults[3][3] = {{'C', 'C', 'A'}, {'A', 'B', 'A'}, {'A', 'A', 'A'}};
+    // Cout >= 48: 64 x 256 (C); Cout < 48: register pipeline; transposed conv: LDS-DMA (B) for every width
+    const char defaults[3][3] = {{'C', 'C', 'A'}, {'A', 'B', 'B'}, {'A', 'A', 'A'}};
     for (int m = 0; m < 3; ++m)
       for (int c = 0; c < 3; ++c) {
         char name[32];
@@ -964,9 +1011,11 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
   char v = mc_variant(mode, cfg);
   // the large-tile variants need enough tiles to fill the chip twice over (2 blocks per CU); smaller launches keep
   // the 128-position tiles (and their split-K plan)
+  // (mid-size launches — 16^2 .. 32^2 at B=8 — then take the LDS-DMA pipeline on the 128-position tile: 119 vs 126 us
+  // and 380 vs 396 us; below ~1500 positions the register pipeline is as fast or faster)
   if (mode == 0 && v == 'C' && cfg < 2 &&
       (p.ksplit > 1 || blocks_with(p, cfg == 0 ? 128 : 64, 256) < 2LL * FMGAN_NUM_CU || p.rgb_out))
-    v = 'A';
+    v = (!p.rgb_out && (long long)p.batch * p.h * p.w >= 1536) ? 'B' : 'A';
   int st = 1;
   if (mode == 0) {
     switch (cfg) {
@@ -1068,7 +1117,9 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad_f32(const WGParams p) {
   const int SB = PH * PWP + 1 + ((PH * PWP) & 1);   // odd stride: conflict-free across i
   float* Gz = smem;                            // [32][SA]
   float* Us = smem + 32 * SA;                  // [32][SB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave index as an SGPR: LDS-DMA destinations (M0), piece guards and tile offsets derived from it stay scalar
+  // (left in a VGPR, every `buffer_load ... lds` sat in a waterfall loop with v_readfirstlane)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
   const int o_tile = lb % p.o_tiles;
@@ -1201,7 +1252,9 @@ __global__ __launch_bounds__(256, 2) void modconv_wgrad64_f32(const WG64Params p
   extern __shared__ float smem[];
   float* As = smem;               // [64][PA]
   float* Bs = smem + 64 * PA;     // [64][PB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave index as an SGPR: LDS-DMA destinations (M0), piece guards and tile offsets derived from it stay scalar
+  // (left in a VGPR, every `buffer_load ... lds` sat in a waterfall loop with v_readfirstlane)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
   const int aq = wave >> 1, bq = wave & 1;
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
