@@ -481,28 +481,42 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // (hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) in front of each group of four:
   // the sched_barriers keep "issue all reads of stage st+1, then run stage st's MFMAs" as written.)
   // hook(st): extra issue work placed in front of stage st's MFMAs (PIPE 1: a slice of the next chunk's DMA pieces)
+  // Two operand sets used alternately (NSTAGE is even): with one `cur = nxt` copy per stage the compiler kept the copies
+  // as real v_mov_b64 (112 dwords per chunk on the transposed tile).
+  static_assert(NSTAGE % 2 == 0, "stages are processed in pairs");
   auto contract = [&](auto&& hook, auto all_taps) {
-    Ops cur, nxt;
-    fetch(cur, 0);
+    Ops o0, o1;
+    fetch(o0, 0);
 #pragma unroll
-    for (int st = 0; st < NSTAGE; ++st) {
+    for (int st = 0; st < NSTAGE; st += 2) {
       __builtin_amdgcn_sched_barrier(0);
       hook(st);
-      if (st + 1 < NSTAGE) {
-        fetch(nxt, st + 1);
-        if constexpr (PIPE == 1 && MODE != 1) {
-          // the style value of a channel pair is read with its first tap row and reused for the other two
-          if ((st + 1) % 3 != 0) {
+      fetch(o1, st + 1);
+      if constexpr (PIPE == 1 && MODE != 1) {
+        // the style value of a channel pair is read with its first tap row and reused for the other two
+        if ((st + 1) % 3 != 0) {
 #pragma unroll
-            for (int g = 0; g < RNP; ++g) nxt.s[g] = cur.s[g];
+          for (int g = 0; g < RNP; ++g) o1.s[g] = o0.s[g];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      modulate(o0);
+      mma(o0, all_taps);
+      __builtin_amdgcn_sched_barrier(0);
+      hook(st + 1);
+      if (st + 2 < NSTAGE) {
+        fetch(o0, st + 2);
+        if constexpr (PIPE == 1 && MODE != 1) {
+          if ((st + 2) % 3 != 0) {
+#pragma unroll
+            for (int g = 0; g < RNP; ++g) o0.s[g] = o1.s[g];
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      modulate(cur);
-      mma(cur, all_taps);
+      modulate(o1);
+      mma(o1, all_taps);
       __builtin_amdgcn_sched_barrier(0);
-      if (st + 1 < NSTAGE) cur = nxt;
     }
   };
 
