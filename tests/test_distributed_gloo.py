@@ -4,6 +4,7 @@ import os
 import sys
 
 import pytest
+import numpy as np
 import torch
 import torch.multiprocessing as mp
 
@@ -16,6 +17,26 @@ def _toy_modules():
     for name, m in (('lin', lin), ('lin2', lin2), ('dead', dead)):
         m.load_state_dict({k: synth.tensor(f'toy/{name}/{k}', v.shape) for k, v in m.state_dict().items()})
     return lin, lin2, dead
+
+
+def _by_value(v):
+    if torch.is_tensor(v):
+        return v.detach().cpu().numpy()
+    if isinstance(v, dict):
+        return {k: _by_value(x) for k, x in v.items()}
+    if isinstance(v, (tuple, list)):
+        return type(v)(_by_value(x) for x in v)
+    return v
+
+
+def _tensors(v):
+    if isinstance(v, np.ndarray):
+        return torch.from_numpy(v)
+    if isinstance(v, dict):
+        return {k: _tensors(x) for k, x in v.items()}
+    if isinstance(v, (tuple, list)):
+        return type(v)(_tensors(x) for x in v)
+    return v
 
 
 def _worker(rank, world, port, q):
@@ -111,7 +132,9 @@ def _worker_body(rank, world, port, q):
     assert not bad, bad[0]
     # (one style head: the pyramid's lateral layers are unused and have no gradient)
     res['grad_psp'] = torch.cat([p.grad.reshape(-1) for p in enc.parameters() if p.grad is not None])[::4999].clone()
-    q.put((rank, res))
+    # tensors cross the queue BY VALUE (numpy): a torch tensor travels as a shared-memory file that the parent opens
+    # lazily, and a worker that has already exited by then leaves it a FileNotFoundError
+    q.put((rank, _by_value(res)))
     D.synchronize()
     torch.distributed.destroy_process_group()
 
@@ -131,7 +154,7 @@ def test_world_size_2_gloo():
     for _ in range(2):
         r, res = q.get(timeout=500)
         assert 'error' not in res, res.get('error')
-        out[r] = res
+        out[r] = _tensors(res)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
