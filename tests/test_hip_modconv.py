@@ -1,4 +1,6 @@
 """GPU parity tests for the modulated convolution / ToRGB kernels and the modules built on them."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -509,3 +511,48 @@ def test_strided_wgrad_kernel_vs_fp64(shape):
     ref = ref * 0.37
     torch.testing.assert_close(gw.double(), ref, atol=2e-5 * float(ref.abs().max()), rtol=2e-5)
     assert torch.equal(gw, _native.modconv_wgrad(go, d, x, s, 0.37, mode=mode))      # bit-reproducible
+
+
+_LOOP_WORKER = r'''
+import hashlib, json, os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, '3d-fm-gan_amd')):
+    sys.path.insert(0, p)
+import torch
+from op import _native
+d = torch.device('cuda', 0)
+out = {}
+# (res, cin, cout, mode, batch): lean-loop shapes of every LDS-DMA tile, a ragged-channel shape and a tiny one (general loop both times)
+for (r, cin, cout, mode, b) in [(64, 128, 128, 0, 4), (32, 64, 64, 0, 8), (32, 32, 32, 0, 8), (32, 128, 64, 1, 4),
+                                (64, 64, 32, 1, 2), (33, 40, 72, 0, 3), (17, 24, 48, 1, 2), (8, 64, 64, 0, 2)]:
+    g = torch.Generator(device=d).manual_seed(r * 7 + mode)
+    x = torch.randn(b, cin, r, r, device=d, generator=g)
+    w = torch.randn(cout, cin, 3, 3, device=d, generator=g)
+    s = torch.randn(b, cin, device=d, generator=g) * 0.5 + 1
+    wt = _native.modconv_weight_prep(w, 1.0 / (cin * 9) ** 0.5)
+    dm = _native.modconv_demod(w, s, 1.0 / (cin * 9) ** 0.5)
+    y = _native.modconv2d(x, wt, s, dm, mode)
+    out[f'{r}/{cin}/{cout}/{mode}/{b}'] = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()
+print('DIGESTS ' + json.dumps(out))
+'''
+
+
+def test_lean_k_loop_equals_general_k_loop_bitwise(tmp_path):
+    """csrc/modconv.hip, PIPE 1: the lean K loop (taken when every chunk is complete and DMA-servable) against the general
+    loop (FMGAN_MC_DEBUG=8 forces it; the library reads the switch once, hence two processes): same DMA pieces, same
+    MFMA order -> identical output bits on every tile family."""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / 'loop_worker.py'
+    script.write_text(_LOOP_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for dbg in ('0', '8'):
+        env = dict(os.environ, FMGAN_MC_DEBUG=dbg)
+        pr = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in pr.stdout.splitlines() if ln.startswith('DIGESTS ')]
+        assert pr.returncode == 0 and line, pr.stdout[-1000:] + pr.stderr[-3000:]
+        res.append(json.loads(line[0][8:]))
+    assert res[0] == res[1]
+    assert len(res[0]) == 8
