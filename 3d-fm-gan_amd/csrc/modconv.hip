@@ -643,7 +643,9 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     // chunk and per stage (spread / dma_ok / debug bits, the larger-than-main-tile piece loops with their div/mod
     // address maths, one wave-uniform branch per tap in MODE 1), ~1300 scalar and vector instructions around the 60-72
     // MFMAs of a chunk on the small tiles.  Same DMA pieces, same MFMA order: identical bits.
-    // (FMGAN_MC_DEBUG bit 3 forces the general loop: A/B measurements.)
+    // (FMGAN_MC_DEBUG bit 3 forces the general loop: A/B measurements.  Unrolling the lean loop by two chunks, so that the
+    // double buffer's index is a compile-time constant in each half, was measured too: no gain — 12.19 vs 12.10-12.13 ms over
+    // the 17 layers — and 24-31 more spilled SGPRs; not kept.)
     const bool lean = fastc && p.debug == 0 && i_begin < i_end && ((i_end - i_begin) % KC) == 0 && x_pieces <= 4 * NUP &&
                       s_pieces <= 4 && tapmask == 0x1FFu;
     if (lean) {
