@@ -970,10 +970,11 @@ inline char mc_variant(int mode, int cfg) {
   static bool init = false;
   if (!init) {
     // measured on MI355X (profiles/r02_modconv_variants.md): plain conv, Cout >= 96: 128 x 256 tile by LDS-DMA (C);
-    // Cout >= 48: 64 x 256 (C); Cout < 48: LDS-DMA on the 32 x 128 tile (B: a tie with the register pipeline stand-alone,
-    // 1791 vs 1807 us at 1024^2, +0.5..1 % over all layers in a step, where the last layer also carries the RGB epilogue);
-    // transposed conv: LDS-DMA (B) for every width
-    const char defaults[3][3] = {{'C', 'C', 'B'}, {'A', 'B', 'B'}, {'A', 'A', 'A'}};
+    // Cout >= 48: 64 x 256 in 4-channel chunks, three blocks per CU (C; 1470 -> 1390 us at 512^2 against 8-channel chunks
+    // at two blocks per CU, possible since the scalar wave index freed ~25 VGPRs); Cout < 48: 32 x 256, three blocks per CU
+    // (C: 1701 us at 1024^2; 32 x 128 by LDS-DMA 1809, register pipeline 1760-1790, 32 x 512 1873);
+    // transposed conv: LDS-DMA (B) for every width (a 4-block form of its 32-channel tile spills and loses 2 %)
+    const char defaults[3][3] = {{'C', 'C', 'C'}, {'A', 'B', 'B'}, {'A', 'A', 'A'}};
     for (int m = 0; m < 3; ++m)
       for (int c = 0; c < 3; ++c) {
         char name[32];
@@ -1031,9 +1032,11 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
   // the 128-position tiles (and their split-K plan)
   // (mid-size launches — 16^2 .. 32^2 at B=8 — then take the LDS-DMA pipeline on the 128-position tile: 119 vs 126 us
   // and 380 vs 396 us; below ~1500 positions the register pipeline is as fast or faster)
-  if (mode == 0 && v == 'C' && cfg < 2 &&
-      (p.ksplit > 1 || blocks_with(p, cfg == 0 ? 128 : 64, 256) < 2LL * FMGAN_NUM_CU || p.rgb_out))
-    v = (!p.rgb_out && (long long)p.batch * p.h * p.w >= 1536) ? 'B' : 'A';
+  if (mode == 0 && v == 'C') {
+    const bool small = p.ksplit > 1 || blocks_with(p, cfg == 0 ? 128 : (cfg == 1 ? 64 : 32), 256) < 2LL * FMGAN_NUM_CU;
+    if (cfg < 2 && (small || p.rgb_out)) v = (!p.rgb_out && (long long)p.batch * p.h * p.w >= 1536) ? 'B' : 'A';
+    else if (cfg == 2 && small) v = 'B';
+  }
   int st = 1;
   if (mode == 0) {
     switch (cfg) {
@@ -1043,11 +1046,11 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
         return st != 1 ? st : launch_cfg<0, 2, 2, 2, 2>(p, s);
       case 1:
         if (v == 'B') st = launch_cfg<0, 2, 1, 1, 4, 3, 8, 1>(p, s);
-        else if (v == 'C') st = launch_cfg<0, 2, 2, 1, 4, 2, 8, 1>(p, s);                      // 64 x 256
+        else if (v == 'C') st = launch_cfg<0, 2, 2, 1, 4, 3, 4, 1>(p, s);                      // 64 x 256, 4-channel chunks: 3 blocks per CU
         return st != 1 ? st : launch_cfg<0, 2, 1, 1, 4, 3>(p, s);
       default:
         if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
-        else if (v == 'C') st = launch_cfg<0, 1, 4, 1, 4, 2, 8, 1>(p, s);                      // 32 x 512
+        else if (v == 'C') st = launch_cfg<0, 1, 2, 1, 4, 3, 8, 1>(p, s);                      // 32 x 256, 3 blocks per CU
         return st != 1 ? st : launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
     }
   }
