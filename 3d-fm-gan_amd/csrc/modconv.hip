@@ -1002,6 +1002,9 @@ inline int pick_cfg(int mode, int cout, long long positions) {
     return cout >= 96 ? 0 : (cout >= 48 ? 1 : 2);
   }
   if (mode == 2) return cout >= 96 ? 0 : (cout >= 48 ? 1 : 2);   // stride-2 patches are 4x larger: 128 positions only
+  // transposed conv: the 32-channel tile (three blocks per CU) also serves the widest layers once they are large
+  // enough (Cout 256-512 at 32^2-64^2, B=8: 518 -> 501 and 850 -> 808 us); a tie at Cout 64-128, slower below 4096 positions
+  if (cout >= 192 && positions >= 4096) return 2;
   return cout >= 48 ? 1 : 2;
 }
 
