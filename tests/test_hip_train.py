@@ -114,7 +114,11 @@ def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=None,
             # completely (|sum| / sum|terms| ~ 1e-4, tools/measure_parity.py prints it); its relative error is the
             # relative error of the upstream gradient amplified by that cancellation.  Measured 2.0e-3 (reference 1e-4).
             fl = fn = FLOOR_SCALAR
-        if kinks is not None and e_hip > margin * e_ref + fl and e_hip <= KINK_MAX and en_hip <= margin * en_ref + KINK_NORM:
+        over = e_hip > margin * e_ref + fl or en_hip > margin * en_ref + fn
+        if kinks is not None and over and e_hip <= KINK_MAX and en_hip <= margin * en_ref + KINK_NORM:
+            # (a flipped unit of a tiny layer — an SE gate's ReLU has B x C/16 outputs — moves a whole row of the weight
+            # gradient: the strided sample may miss it while the norm shows it, e.g. ppl/e_wp/body.0.res_layer.5.fc1.weight
+            # norm 1.3e-3 off in one run)
             kinks.append((key, e_hip, en_hip))
         else:
             assert e_hip <= margin * e_ref + fl, f'{key}: sample err {e_hip:.3e} vs reference-fp32 err {e_ref:.3e}'
