@@ -43,7 +43,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MARGIN, FLOOR, FLOOR_MIOPEN, FLOOR_NORM, FLOOR_SCALAR = 4.0, 1e-3, 2e-2, 5e-4, 8e-3
-KINK_TENSORS, KINK_MAX, KINK_NORM = 3, 0.1, 2e-2
+KINK_TENSORS, KINK_MAX, KINK_NORM = 6, 0.1, 2e-2     # one flip shows in the weight AND the bias gradient of its layer
 
 
 def dev():
