@@ -38,6 +38,15 @@ __device__ __forceinline__ void dma_to_lds(RSRC rsrc, float* lds, unsigned voff,
 #endif
 }
 
+// A pointer / word the compiler cannot prove wave-uniform (it came through a runtime-indexed segment table), declared
+// uniform: buffer resources built from it stay in SGPRs instead of sending every buffer_load through a waterfall loop.
+__device__ __forceinline__ const float* uniform_ptr(const float* q) {
+  const unsigned long long v = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned uniform_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // ------------------------------------------------------------------ demod
 // PRE: W is the per-(o,i) sum of squared taps [cout][cin] (modconv_wsq_f32, cached with the weight) instead of the
 // raw weight — the same fma chains in the same order, so both variants give identical bits.
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   constexpr int NWV = (KC * 9 * (BM / 4) + 255) / 256;
   const int spatial = seg_nb * plane;                              // patch slots per channel
   // element offsets are 32-bit, relative to the tile's first sample (host checks nb*cin*h*w < 2^31)
-  const float* in_b0 = p.in + (long long)b0 * p.cin * hw;
-  const float* style_b0 = p.style + (long long)b0 * p.cin;
+  const float* in_b0 = uniform_ptr(p.in + (long long)b0 * p.cin * hw);
+  const float* style_b0 = uniform_ptr(p.style + (long long)b0 * p.cin);
   int gofs[NU], lofs[NU], sofs[NU]; bool inb[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -310,8 +319,8 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   constexpr long long PARK = 0xFFFFFFF0LL;
   const bool fastw = wvec && o0 + BM <= p.cout && (long long)p.cin * 9 * p.cout * 4 < PARK;
   const bool fastx = (long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4 < PARK;
-  const unsigned w_bytes = (unsigned)((long long)p.cin * 9 * p.cout * 4);
-  const unsigned x_bytes = (unsigned)((long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4);
+  const unsigned w_bytes = uniform_u32((unsigned)((long long)p.cin * 9 * p.cout * 4));
+  const unsigned x_bytes = uniform_u32((unsigned)((long long)min(seg_nb, p.batch - b0) * p.cin * hw * 4));
   const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, w_bytes, 0x00020000);
   const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b0), 0, x_bytes, 0x00020000);
   unsigned wofs[NWV], xofs[NU];
