@@ -339,6 +339,7 @@ struct DRParams {
   long long ps;
   int th, strips, tiles_y; long long total_waves;
   float alpha, act_scale;
+  int reverse;
 };
 
 template <int SIZE, int AUX, typename RSRC>   // AUX: cache policy bits of the load (gfx940+: 2 = nt, streaming)
@@ -377,7 +378,9 @@ __global__ __launch_bounds__(256) void ufd_dmaring_f32(const DRParams p) {
   const int strip = (int)(gw % p.strips);
   const long long t = gw / p.strips;
   const int ty = (int)(t % p.tiles_y);
-  const long long plane = t / p.tiles_y;
+  // planes in DESCENDING order: inside a step the input was written a moment ago by the transposed conv, sample 0 first;
+  // its last ~256 MB are still in the Infinity Cache when the blur starts, so the blur begins where the producer ended
+  const long long plane = p.reverse ? p.planes - 1 - t / p.tiles_y : t / p.tiles_y;
   float* ring = ufd_ring + wv * (4 * SLOT);
 
   // flipped taps, zero-extended to 4x4 (wave-uniform -> SGPRs)
@@ -697,6 +700,7 @@ int launch_dmaring(const void* in, const void* kern, void* out, const UfdParams&
   // order, 1.51x with nt loads on top, 1.12x in hardware order; plain blur 1.08x either way).
   const char* e = getenv("FMGAN_UFD_DMA");
   const char mode = e ? e[0] : '1';
+  r.reverse = (e && e[0] == 'f') ? 0 : 1;   // 'f': ascending plane order (measurements)
   if (mode == 'x') {
     if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, true, true>), g, b, lds, s, r);
     else hipLaunchKernelGGL((ufd_dmaring_f32<false, true, true>), g, b, lds, s, r);
