@@ -339,7 +339,6 @@ struct DRParams {
   long long ps;
   int th, strips, tiles_y; long long total_waves;
   float alpha, act_scale;
-  int reverse;
 };
 
 template <int SIZE, int AUX, typename RSRC>   // AUX: cache policy bits of the load (gfx940+: 2 = nt, streaming)
@@ -377,14 +376,8 @@ __global__ __launch_bounds__(256) void ufd_dmaring_f32(const DRParams p) {
   if (gw >= p.total_waves) return;  // wave-uniform
   const int strip = (int)(gw % p.strips);
   const long long t = gw / p.strips;
-  const int ty = (p.reverse & 2) ? p.tiles_y - 1 - (int)(t % p.tiles_y) : (int)(t % p.tiles_y);
-  // Planes in DESCENDING order (reverse bit 0; bit 1 would reverse the row tiles instead).  Measured in a step, where the
-  // input was written a moment ago by the transposed conv (same box, tools/exp/ab_dma.sh "1 r y f"): ascending/ascending
-  // 4.72-4.74 TB/s, planes descending 5.09-5.10, row tiles descending 5.08, BOTH descending 4.73-4.79; stand-alone (no
-  // producer) all four orders take the same 445 us.  So it is the relation to what the producer left in the caches, not
-  // the order as such — which residency exactly (the parity behaviour rules out plain "most recent first") is not
-  // established; the better order is kept because it is free.
-  const long long plane = (p.reverse & 1) ? p.planes - 1 - t / p.tiles_y : t / p.tiles_y;
+  const int ty = (int)(t % p.tiles_y);
+  const long long plane = t / p.tiles_y;
   float* ring = ufd_ring + wv * (4 * SLOT);
 
   // flipped taps, zero-extended to 4x4 (wave-uniform -> SGPRs)
@@ -704,7 +697,6 @@ int launch_dmaring(const void* in, const void* kern, void* out, const UfdParams&
   // order, 1.51x with nt loads on top, 1.12x in hardware order; plain blur 1.08x either way).
   const char* e = getenv("FMGAN_UFD_DMA");
   const char mode = e ? e[0] : '1';
-  r.reverse = (e && e[0] == 'f') ? 0 : ((e && e[0] == 'r') ? 3 : ((e && e[0] == 'y') ? 2 : 1));   // 'f' ascending planes; 'r'/'y': experiments with descending row tiles
   if (mode == 'x') {
     if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, true, true>), g, b, lds, s, r);
     else hipLaunchKernelGGL((ufd_dmaring_f32<false, true, true>), g, b, lds, s, r);

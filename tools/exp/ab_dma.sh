@@ -1,27 +1,28 @@
 #!/bin/bash
 # In-step A/B of the headline blur's launch modes (FMGAN_UFD_DMA): bench.py's roofline object + FETCH_SIZE per launch.
-# usage (GPU box): bash tools/exp/ab_dma.sh "1 n x 0"
+# usage (GPU box): bash tools/exp/ab_dma.sh "1 0" [reps]
+# NOTE: the in-step timing of this kernel is BIMODAL between consecutive process launches (4.65 vs 5.1 TB/s on one box,
+# alternating from one launch of the same command to the next: physical placement of the two 1 GB buffers), so the
+# modes are run in a palindromic order (a b b a a b b a ...) and every variant needs several launches.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-MODES=${1:-"1 n x 0"}
+MODES=${1:-"1 0"}
+REPS=${2:-2}
 rm -f $R/gpurun_out/ab_dma_*.json
-for rep in 1 2; do for m in $MODES; do
-  FMGAN_UFD_DMA=$m python3 $R/bench.py --no-cpu-baseline --no-secondary --no-train > $R/gpurun_out/ab_dma_${m}_$rep.json 2> $R/gpurun_out/ab_dma_$m.err
-done; done
-for m in $MODES; do
-  export FMGAN_UFD_DMA=$m
-  rm -rf $R/gpurun_out/ab_fetch_$m
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/ab_fetch_$m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-train > /dev/null 2> $R/gpurun_out/ab_fetch_$m.err
-done
+FWD="$MODES"; REV=$(echo $MODES | tr ' ' '\n' | tac | tr '\n' ' ')
+i=0
+for rep in $(seq 1 $REPS); do for seq in "$FWD" "$REV"; do for m in $seq; do
+  i=$((i+1))
+  FMGAN_UFD_DMA=$m python3 $R/bench.py --no-cpu-baseline --no-secondary --no-train > $R/gpurun_out/ab_dma_${m}_$i.json 2> $R/gpurun_out/ab_dma_$m.err
+done; done; done
 python3 - <<PY
-import json,glob,csv
+import json,glob,re
 R="$R"
-for f in sorted(glob.glob(f"{R}/gpurun_out/ab_dma_*_*.json")):
+res={}
+for f in sorted(glob.glob(f"{R}/gpurun_out/ab_dma_*_*.json"), key=lambda f:int(re.findall(r'_(\d+)\.json',f)[0])):
     d=json.loads(open(f).read().strip().splitlines()[-1])
-    print(f.split("/")[-1],"pairs/s",round(d["value"],1),"headline GB/s",round(d["roofline"]["achieved"]),"frac",round(d["roofline"]["frac"],4))
-for d in sorted(glob.glob(f"{R}/gpurun_out/ab_fetch_*/")):
-    for f in glob.glob(d+"**/*counter_collection.csv", recursive=True):
-        v=[float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"]=="FETCH_SIZE" and ("ufd_dmaring" in r["Kernel_Name"] or "ufd_rowmarch_f32<4" in r["Kernel_Name"]) and r["Grid_Size"]=="1048576"]
-        v=v[:3]   # the first launches are the in-step ones (bench.py's standalone op comes last)
-        print(d.split("/")[-2],"FETCH_SIZE KiB/launch",[round(x) for x in v])
+    m=f.split("/")[-1].split("_")[2]
+    res.setdefault(m,[]).append(round(d["roofline"]["achieved"]))
+    print(f.split("/")[-1],"pairs/s",round(d["value"],1),"headline GB/s",round(d["roofline"]["achieved"]))
+for m,v in res.items(): print("mode",m,"launches",v,"mean",round(sum(v)/len(v)))
 PY
