@@ -72,6 +72,22 @@ def test_invalid_arguments_return_status_without_gpu():
     assert L.fmgan_upfirdn2d(0, None, None, None, 0, 8, 8, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, -1, None) == 0
 
 
+def test_prelu_backward_host_logic():
+    """fmgan_prelu_backward_blocks / _f32: partial-sum rows per launch and argument checks, all before any HIP call."""
+    L = _lib()
+    assert L.fmgan_prelu_backward_blocks(0, 64) == 0 and L.fmgan_prelu_backward_blocks(10, 0) == 0
+    for rows, c in ((1, 64), (1 << 20, 64), (1 << 20, 512), (300, 96), (7, 2048)):
+        b = L.fmgan_prelu_backward_blocks(rows, c)
+        q = 1
+        while q < c // 4 and q < 256:
+            q *= 2
+        assert 1 <= b <= max(1, -(-rows // (256 // q))) and b <= 256 * 8        # never more blocks than row groups / 8 per CU
+    assert L.fmgan_prelu_backward_f32(None, None, None, None, None, 0, 64, None) == 0          # empty: nothing to do
+    assert L.fmgan_prelu_backward_f32(None, None, None, None, None, 16, 64, None) == -1        # null pointers
+    assert L.fmgan_prelu_backward_f32(None, None, None, None, None, 16, 6, None) == -2         # channels % 4: unsupported
+    assert L.fmgan_prelu_backward_f32(None, None, None, None, None, -1, 64, None) == -1
+
+
 def test_product_has_no_cpu_path():
     from op import upfirdn2d, fused_leaky_relu, FusedLeakyReLU
     x = torch.randn(1, 2, 8, 8)
