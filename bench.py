@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — (photo, render) pairs/s of the 3D-FM GAN forward hot path on MI355X, with the upfirdn2d roofline.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 under torch.distributed.run (RANK / WORLD_SIZE in the environment): this process is one of the N ranks.  N>1 started
+plainly: this process touches no GPU, starts the N ranks itself as children (one per GPU, rendezvous on 127.0.0.1) and
+relays rank 0's line — the reference goes multi-GPU from one command too (train_3_encoder.py:355-362).  A rank count that
+differs from --gpus is an error, never a silently smaller run.
 
 A "step" is one forward of the hot path over one batch of synthetic (photo, render) pairs per GPU:
 E_Tsr + E_W + E_W_Plus on 256^2 images -> co-modulation -> Generator -> image, fp32, eval-mode BatchNorm, no_grad.
@@ -195,6 +200,15 @@ def train_leg(name, steps, world, timeout_s):
     return json.loads(lines[-1])
 
 
+def dist_info(world):
+    """What the process group itself reports (not what was asked for): backend and rank count."""
+    if world > 1 and dist.is_initialized():
+        return {'backend': 'rccl (torch backend "nccl")' if dist.get_backend() == 'nccl' else dist.get_backend(),
+                'ranks': dist.get_world_size(), 'launcher': 'bench.py self-launch' if os.environ.get('FMGAN_SELF_LAUNCHED')
+                else 'external (torch.distributed.run)'}
+    return {'backend': None, 'ranks': 1, 'launcher': None}
+
+
 def timed(step, steps, warmup, world):
     for _ in range(warmup):
         step()
@@ -343,12 +357,54 @@ def cpu_baseline_items(sds, photo, render, size):
     return items
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of a parent that never initialises
+    the GPU (no exec from a process that did), one rank per GPU, and exit with the worst child's code.  Rank 0's stdout
+    (the JSON line) is the parent's stdout; every rank's stderr passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FMGAN_SELF_LAUNCHED='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in alive:          # a dead rank leaves the others in a collective: end exactly those PIDs
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def check_world(args, world):
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the job has {world} rank(s) (WORLD_SIZE='
+                         f"{os.environ.get('WORLD_SIZE', 'unset')}): refusing to report a run of a different size")
+
+
 def plumbing(args):
     """Everything of an N-rank bench run except the model: env rendezvous (gloo without GPUs), the shard of the global
     batch this rank owns, warm-up, barrier-bracketed timing, MAX over ranks, one JSON line on rank 0."""
     from Miscellaneous import distributed as D
     rank, world, device = D.init_distributed()
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    check_world(args, world)
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl['batch']
     lo, hi = D.shard_range(batch * world)
@@ -368,7 +424,7 @@ def plumbing(args):
                           'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
                           'vs_baseline': None, 'dtype': 'f32', 'data': 'plumbing test: no model, stand-in step',
                           'config': {'workload': f'{args.workload} (plumbing only)', 'pairs_per_gpu': batch,
-                                     'global_pairs': batch * world, 'backend': dist.get_backend() if world > 1 else None}}))
+                                     'global_pairs': batch * world, **dist_info(world)}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -389,6 +445,8 @@ def main():
     ap.add_argument('--plumbing', action='store_true', help='no GPU work: a stand-in step through the same rendezvous, '
                     'sharding, barrier + MAX-over-ranks timing and JSON contract (CPU/gloo test of the N>1 launch path)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     if args.plumbing:
         return plumbing(args)
 
@@ -408,7 +466,7 @@ def main():
         os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
     rank, world, device = D.init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    check_world(args, world)
     _native.lib()
 
     wl = WORKLOADS[args.workload]
@@ -435,7 +493,8 @@ def main():
                 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
-                           'image_size': wl['size'], 'parallelism': f'dp{world} (DDP, 256 MiB buckets)' if world > 1 else 'single GPU'}}))
+                           'image_size': wl['size'], 'parallelism': f'dp{world} (DDP, 256 MiB buckets)' if world > 1 else 'single GPU',
+                           **dist_info(world)}}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -468,7 +527,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
                    'image_size': wl['size'], 'parallelism': f'replicas x{world} (batch-sharded, no collective)',
-                   'launch': 'eager' if graphed is None else 'hip-graph replay of the whole forward'},
+                   'launch': 'eager' if graphed is None else 'hip-graph replay of the whole forward', **dist_info(world)},
         'eager': {'value': world * batch * args.steps / dt_eager, 'ms_per_step': 1e3 * dt_eager / args.steps},
     }
 

@@ -229,6 +229,35 @@ def test_bench_two_rank_launch_plumbing():
     assert abs(rec['value'] - rec['config']['global_pairs'] / (rec['ms_per_step'] * 1e-3)) < 1e-6 * rec['value']
 
 
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2 --plumbing`, no external launcher and no WORLD_SIZE: the parent starts the two
+    ranks itself and relays rank 0's line, which must say n_gpus == 2 with the rank count the process group reports."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
+                           '--plumbing'], capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, proc.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['ranks'] == 2 and rec['config']['backend'] == 'gloo'
+    assert rec['config']['launcher'] == 'bench.py self-launch'
+    assert rec['ms_per_step'] >= 4.0
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_a_rank_count_other_than_gpus():
+    """--gpus 2 inside a job of ONE rank (WORLD_SIZE=1) must fail instead of printing a 1-GPU line labelled otherwise."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0',
+                           '--plumbing'], capture_output=True, text=True, timeout=100, cwd=ROOT, env=env)
+    assert proc.returncode != 0
+    assert 'refusing' in proc.stderr and not [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+
+
 def test_single_process_helpers_are_noops():
     sys.path.insert(0, os.path.join(ROOT, '3d-fm-gan_amd'))
     from Miscellaneous import distributed as D
