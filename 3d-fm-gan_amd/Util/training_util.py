@@ -1,9 +1,10 @@
 """Adversarial losses and regularisers of the training step (reference: Util/training_util.py:24-58, 103-113).
 
-Only the pieces the hot path's callers need: the non-saturating logistic GAN pair, R1 on real images, the path-length
-regulariser and the L1 reconstruction loss.  R1 and path length differentiate *through* a first derivative, i.e. they
-exercise the double-backward of the HIP ops (upfirdn2d, fused_bias_act) and of the modulated conv.  The perceptual /
-identity / landmark losses of the reference need pretrained third-party networks that are not on this path.
+The pieces the training iteration needs: the non-saturating logistic GAN pair, R1 on real images, the path-length
+regulariser, the L1 reconstruction loss, and the wrappers of the perceptual (LPIPS) and identity (ArcFace) terms
+(Util/training_util.py:115-127, 131-205).  R1 and path length differentiate *through* a first derivative, i.e. they
+exercise the double-backward of the HIP ops (upfirdn2d, fused_bias_act) and of the modulated conv.  The landmark /
+face-region terms need `face_alignment`, a third-party package that is absent offline; they stay out.
 """
 import math
 
@@ -46,6 +47,42 @@ def g_path_regularize(fake_img, latents, mean_path_length, decay=0.01, probe=Non
 def L1_Loss(output_tensor, target_tensor):
     """Mean absolute error between two image batches in [-1, 1] (training_util.py:103-113)."""
     return torch.mean(torch.abs(output_tensor - target_tensor))
+
+
+def LPIPS_Loss(output_tensor, target_tensor, lpips_module):
+    """Batch mean of the LPIPS distance (training_util.py:115-127)."""
+    return torch.mean(lpips_module(output_tensor, target_tensor))
+
+
+RGB_TO_GRAYSCALE_COEF = (0.2989, 0.587, 0.114)
+FACE_ID_LOSS_TYPE = ('MSE', 'CosineSimilarity')
+
+
+def RGB_to_GrayScale(rgb_img):
+    """[N,3,H,W] in [-1,1] -> [N,1,H,W], coefficients and summation order of training_util.py:131-146."""
+    gray = 0
+    for i, c in enumerate(RGB_TO_GRAYSCALE_COEF):
+        gray = gray + c * rgb_img[:, i:i + 1, ...]
+    return gray
+
+
+def Convert_Tensor_For_Face_Recognition_Loss(img_tensor, face_size=128):
+    """Grey image average-pooled to the 128^2 input the ArcFace network is built for (its fc5 takes 512*8*8).  The
+    reference pools by 2 because it trains at 256^2 (training_util.py:148-162); at 1024^2 (BASELINE config 5) its fc
+    layer would not fit, so the pooling factor is size/128 here: identical at 256^2."""
+    gray = RGB_to_GrayScale(img_tensor)
+    k = max(1, img_tensor.shape[-1] // face_size)
+    return F.avg_pool2d(gray, kernel_size=k, stride=k)
+
+
+def Face_Identity_Loss(output_tensor, target_tensor, face_rec_model, loss_type='MSE'):
+    """Distance between the identity features of two image batches (training_util.py:178-205)."""
+    assert loss_type in FACE_ID_LOSS_TYPE
+    target_feature = face_rec_model(Convert_Tensor_For_Face_Recognition_Loss(target_tensor))
+    output_feature = face_rec_model(Convert_Tensor_For_Face_Recognition_Loss(output_tensor))
+    if loss_type == 'MSE':
+        return F.mse_loss(output_feature, target_feature)
+    return torch.mean(1 - F.cosine_similarity(output_feature, target_feature))
 
 
 def requires_grad(model, flag=True):

@@ -247,6 +247,66 @@ extern "C" int fmgan_fused_bias_act(int dtype, const void* x, const void* bias, 
   return launch_generic<__half>(x, bias, refer, out, size_x, size_b, step_b, code, alpha, scale, s);
 }
 
+// ---------------------------------------------------------------- activation backward + bias-gradient partials
+// FusedLeakyReLUFunctionBackward (op/fused_act.py:29-50) is `grad_input = fused_bias_act(grad_output, empty, out, 3, 1,
+// ...)` followed by `grad_input.sum(dims)` for the bias: a second kernel that reads the whole gradient again (667 torch
+// reduce launches, 30 ms per 4 training iterations at 256^2).  Here the pass that writes grad_input also leaves one
+// partial sum per (plane, block): the bias gradient is then a [B, C, blocks] -> [C] sum over a few KB.  Fixed
+// association (per-lane serial, wave butterfly, 4 waves in order): bit-reproducible.
+__global__ __launch_bounds__(256) void fba_bwd_bias_f32(float* __restrict__ gi, float* __restrict__ partial,
+                                                        const float* __restrict__ g, const float* __restrict__ ref,
+                                                        int planes, int step4, float alpha, float scale) {
+  __shared__ float red[4];
+  for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    const long long base = (long long)pl * step4;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g) + base;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(ref) + base;
+    f32x4* o4 = reinterpret_cast<f32x4*>(gi) + base;
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < step4; i += gridDim.x * blockDim.x) {
+      const f32x4 v = g4[i];
+      const f32x4 r = r4[i];
+      f32x4 y;
+      y.x = act_apply<float>(v.x, r.x, 31, alpha) * scale;
+      y.y = act_apply<float>(v.y, r.y, 31, alpha) * scale;
+      y.z = act_apply<float>(v.z, r.z, 31, alpha) * scale;
+      y.w = act_apply<float>(v.w, r.w, 31, alpha) * scale;
+      o4[i] = y;
+      acc += (y.x + y.y) + (y.z + y.w);
+    }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long long)pl * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+}
+
+// blocks per plane the backward pass uses for planes of `hw` elements (= columns of the partial array); 0: shape not
+// served (hw % 4 != 0 or tiny planes) -> the caller keeps the two-step form
+extern "C" int fmgan_fused_bias_act_bwd_blocks(long long planes, int hw) {
+  if (planes <= 0 || hw < 64 || (hw & 3) || planes > 0x7fffffffLL) return 0;
+  int gx = ((hw >> 2) + 1023) / 1024;          // >= 4 float4 per lane
+  if (gx > 64) gx = 64;
+  return gx;
+}
+
+extern "C" int fmgan_fused_bias_act_bwd_f32(const float* grad_out, const float* ref_out, float* grad_in, float* partial,
+                                            long long planes, int hw, float alpha, float scale, void* stream) {
+  if (planes < 0 || hw <= 0) return FMGAN_EINVAL;
+  if (planes == 0) return FMGAN_OK;
+  if (!grad_out || !ref_out || !grad_in || !partial) return FMGAN_EINVAL;
+  const int gx = fmgan_fused_bias_act_bwd_blocks(planes, hw);
+  if (gx == 0 || ((((uintptr_t)grad_out) | ((uintptr_t)ref_out) | ((uintptr_t)grad_in)) & 15) != 0) return FMGAN_EUNSUPPORTED;
+  long long gy = planes;
+  const long long cap = (long long)FMGAN_NUM_CU * 32 / gx;
+  if (gy > cap) gy = cap > 0 ? cap : 1;
+  if (gy > 65535) gy = 65535;
+  hipLaunchKernelGGL(fba_bwd_bias_f32, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, grad_in, partial,
+                     grad_out, ref_out, (int)planes, hw >> 2, alpha, scale);
+  return fmgan_check_launch();
+}
+
 extern "C" int fmgan_noise_bias_act_f32(const float* x, const float* noise, const float* noise_weight,
                                         const float* bias, float* out, int batch, int channel, int hw,
                                         int noise_batch, float alpha, float scale, void* stream) {

@@ -165,6 +165,14 @@ struct MCParams {
   unsigned long long* dbg_clock;
 };
 
+#ifdef FMGAN_EXPERIMENTS
+#define MC_DEBUG(p) ((p).debug)
+#define MC_CLOCK(p) ((p).dbg_clock)
+#else                                   // product build: the ablation branches fold away
+#define MC_DEBUG(p) 0
+#define MC_CLOCK(p) false
+#endif
+
 constexpr int MC_KC = 8;  // input channels per LDS chunk
 
 // demod scale + optional StyledConv epilogue (stylegan2.py:371-373) — shared by the conv epilogue and the split-K finish
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, khalf = lane >> 5;
   unsigned long long clk0 = 0, rt0 = 0;
-  if (p.dbg_clock) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }
+  if (MC_CLOCK(p)) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }
 
   unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
   int si = 0;
@@ -538,10 +546,10 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   if constexpr (PIPE == 0) {
     if (i_begin < i_end) issue(i_begin);
     for (int i0 = i_begin; i0 < i_end; i0 += KC) {
-      const bool live = !(p.debug & 1) || i0 == i_begin;
-      if (!(p.debug & 2)) __syncthreads();            // every wave is done reading the previous chunk
+      const bool live = !(MC_DEBUG(p) & 1) || i0 == i_begin;
+      if (!(MC_DEBUG(p) & 2)) __syncthreads();            // every wave is done reading the previous chunk
       if (live) commit(i0);
-      if (!(p.debug & 2)) __syncthreads();
+      if (!(MC_DEBUG(p) & 2)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       if (live && i0 + KC < i_end) issue(i0 + KC);   // in flight during this chunk's MFMAs
       contract([](int) {}, std::false_type{});
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     // (FMGAN_MC_DEBUG bit 3 forces the general loop: A/B measurements.  Unrolling the lean loop by two chunks, so that the
     // double buffer's index is a compile-time constant in each half, was measured too: no gain — 12.19 vs 12.10-12.13 ms over
     // the 17 layers — and 24-31 more spilled SGPRs; not kept.)
-    const bool lean = fastc && p.debug == 0 && i_begin < i_end && ((i_end - i_begin) % KC) == 0 && x_pieces <= 4 * NUP &&
+    const bool lean = fastc && MC_DEBUG(p) == 0 && i_begin < i_end && ((i_end - i_begin) % KC) == 0 && x_pieces <= 4 * NUP &&
                       s_pieces <= 4 && tapmask == 0x1FFu;
     if (lean) {
       auto piece = [&](int k, int i0, int bufi) {
@@ -705,13 +713,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       // this wave's DMA pieces / LDS stores of chunk i0 have landed; after the barrier everyone's have, and every wave
       // has finished reading the other buffer (its ds_reads were retired before the MFMAs that consumed them)
       __builtin_amdgcn_s_waitcnt(0);
-      if (!(p.debug & 2)) __builtin_amdgcn_s_barrier();
+      if (!(MC_DEBUG(p) & 2)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const int i1 = i0 + KC;
-      const bool more = i1 < i_end && !(p.debug & 1);
+      const bool more = i1 < i_end && !(MC_DEBUG(p) & 1);
       // the next chunk's pieces: spread over this chunk's MFMA stages (each DMA issue then hides behind a matrix
       // instruction of the same wave), or all at once for a chunk the DMA cannot serve / with debug bit 2
-      const bool spread = more && dma_ok(i1) && !(p.debug & 4);
+      const bool spread = more && dma_ok(i1) && !(MC_DEBUG(p) & 4);
       if (more && !spread) stage(i1, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       Wc = smem + buf * bstride;
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       }
     }
   }
-  if (p.dbg_clock && tid == 0 && (blockIdx.x & 63) == 0) {
+  if (MC_CLOCK(p) && tid == 0 && (blockIdx.x & 63) == 0) {
     atomicAdd(p.dbg_clock, __builtin_readcyclecounter() - clk0);
     atomicAdd(p.dbg_clock + 1, wall_clock64() - rt0);
   }
@@ -979,8 +987,14 @@ int launch_cfg(MCParams& p, hipStream_t s) {
 }
 
 // Which pipeline variant serves (mode, cfg): 'A' = register prefetch, 'B'/'C' = LDS-DMA variants.  Defaults are the
-// measured winners (profiles/r02_modconv_variants.md); FMGAN_MC_V<mode><cfg>=A|B|C overrides one entry (experiments).
+// measured winners (profiles/r02_modconv_variants.md).  Only the experiments build (make experiments:
+// -DFMGAN_EXPERIMENTS, tools/exp/lib/libfmgan_hip_exp.so) reads FMGAN_MC_V<mode><cfg>=A|B|C, FMGAN_MC_DEBUG and
+// FMGAN_MC_CLOCKPTR; the product library has no environment switch and no ablation code path.
 inline char mc_variant(int mode, int cfg) {
+#ifndef FMGAN_EXPERIMENTS
+  static const char defaults[3][3] = {{'C', 'C', 'C'}, {'A', 'B', 'B'}, {'A', 'A', 'A'}};   // comments: see below
+  return defaults[mode][cfg];
+#else
   static char table[3][3];
   static bool init = false;
   if (!init) {
@@ -1000,6 +1014,7 @@ inline char mc_variant(int mode, int cfg) {
     init = true;
   }
   return table[mode][cfg];
+#endif
 }
 
 // Tile configurations (output channels x positions per block; blocks per CU the register budget allows):
@@ -1750,6 +1765,7 @@ int modconv2d_impl(const float* in, const float* wt, const float* style, const f
   if (rgb && (!rgb->wmod || !rgb->out)) return FMGAN_EINVAL;
   if (fuse_act && noise && noise_batch != 1 && noise_batch != batch) return FMGAN_EINVAL;
   MCParams p{};
+#ifdef FMGAN_EXPERIMENTS
   {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("FMGAN_MC_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -1758,6 +1774,7 @@ int modconv2d_impl(const float* in, const float* wt, const float* style, const f
     if (clk < 0) { const char* e = getenv("FMGAN_MC_CLOCKPTR"); clk = e ? atoll(e) : 0; }
     p.dbg_clock = (unsigned long long*)clk;
   }
+#endif
   if (rgb) {
     p.rgb_wmod = rgb->wmod; p.rgb_bias = rgb->bias; p.rgb_skip = rgb->skip; p.rgb_out = rgb->out; p.rgb_c = rgb->c;
   }

@@ -654,10 +654,8 @@ struct UfdEpilogue {
 
 // Path 1b serves the aligned-row layout only: position 0 of every row (= logical column -pad_x0) on a 16-byte
 // boundary, row / plane pitch multiples of 4 floats, rows of the output 16-byte aligned, a noise plane when fused.
-// FMGAN_UFD_DMA=0 keeps path 1 (A/B measurements).
+// force_path 4 keeps path 1, 5 insists on path 1b (A/B tests and measurements; no environment switch in the library).
 bool dmaring_ok(const void* in, const void* out, const UfdParams& p, const UfdEpilogue* ep) {
-  const char* e = getenv("FMGAN_UFD_DMA");   // read per call: the tests switch it inside one process
-  if (e && e[0] == '0') return false;
   const uintptr_t in0 = (uintptr_t)in - 4u * (unsigned)p.pad_x0;
   if (p.pad_x0 < 0 || p.pad_x0 > 3 || (in0 & 15) || ((uintptr_t)out & 15)) return false;
   if ((p.in_row_stride & 3) || (p.in_plane_stride & 3) || (p.out_w & 3) || p.out_w < 256 || p.out_h < 8) return false;
@@ -689,30 +687,22 @@ int launch_dmaring(const void* in, const void* kern, void* out, const UfdParams&
   if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
   const dim3 g((unsigned)blocks), b(256);
   const size_t lds = 4 * 4 * 320 * sizeof(float);   // 4 waves x 4 slots x (256 + 64) floats
-  // Block order and cache policy (experiment switch FMGAN_UFD_DMA = n: nt loads, x: XCD-contiguous order + nt loads).
-  // Default: hardware order, cached loads.  Blocks are dealt round-robin over the 8 XCDs, so with tiles numbered
-  // (strip, row tile, plane) an XCD sees the SAME few (strip, row tile) positions of every plane: its share of the
-  // noise plane is a few hundred KB that stays in its L2 for all planes, where the XCD-contiguous order of path 1
-  // re-fetches it per plane (FETCH_SIZE of the fused headline blur, standalone: 1.68x the input with XCD-contiguous
-  // order, 1.51x with nt loads on top, 1.12x in hardware order; plain blur 1.08x either way).
-  const char* e = getenv("FMGAN_UFD_DMA");
-  const char mode = e ? e[0] : '1';
-  if (mode == 'x') {
-    if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, true, true>), g, b, lds, s, r);
-    else hipLaunchKernelGGL((ufd_dmaring_f32<false, true, true>), g, b, lds, s, r);
-  } else if (mode == 'n') {
-    if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, true, false>), g, b, lds, s, r);
-    else hipLaunchKernelGGL((ufd_dmaring_f32<false, true, false>), g, b, lds, s, r);
-  } else {
-    if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, false, false>), g, b, lds, s, r);
-    else hipLaunchKernelGGL((ufd_dmaring_f32<false, false, false>), g, b, lds, s, r);
-  }
+  // Block order and cache policy: hardware order, cached loads.  Blocks are dealt round-robin over the 8 XCDs, so with
+  // tiles numbered (strip, row tile, plane) an XCD sees the SAME few (strip, row tile) positions of every plane: its
+  // share of the noise plane is a few hundred KB that stays in its L2 for all planes, where the XCD-contiguous order of
+  // path 1 re-fetches it per plane (FETCH_SIZE of the fused headline blur, standalone: 1.68x the input with
+  // XCD-contiguous order, 1.51x with nt loads on top, 1.12x in hardware order; plain blur 1.08x either way — the
+  // <.., NT, XCD> instantiations those numbers came from are no longer built).
+  if (ep) hipLaunchKernelGGL((ufd_dmaring_f32<true, false, false>), g, b, lds, s, r);
+  else hipLaunchKernelGGL((ufd_dmaring_f32<false, false, false>), g, b, lds, s, r);
   return fmgan_check_launch();
 }
 
+// variant: -1 / 1 pick between path 1 and 1b, 4 = path 1 (register row-march), 5 = path 1b (LDS-DMA ring) or refuse
 int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s,
-                    const UfdEpilogue* ep = nullptr) {
-  if (dmaring_ok(in, out, p, ep)) return launch_dmaring(in, kern, out, p, s, ep);
+                    const UfdEpilogue* ep = nullptr, int variant = -1) {
+  if (variant == 5 && !dmaring_ok(in, out, p, ep)) return FMGAN_EUNSUPPORTED;
+  if (variant != 4 && dmaring_ok(in, out, p, ep)) return launch_dmaring(in, kern, out, p, s, ep);
   RMParams r{};
   if (ep) {
     r.fuse = 1; r.noise = ep->noise; r.noise_weight = ep->noise_weight; r.bias = ep->bias;
@@ -857,8 +847,10 @@ extern "C" int fmgan_upfirdn2d_strided(int dtype, const void* input, const void*
       if (dtype == FMGAN_F64) return launch_generic<double>(input, kernel, out, p, s);
       return launch_generic<__half>(input, kernel, out, p, s);
     case 1:
+    case 4:
+    case 5:
       if (!rowmarch_ok(dtype, p)) return FMGAN_EUNSUPPORTED;
-      return launch_rowmarch(input, kernel, out, p, s);
+      return launch_rowmarch(input, kernel, out, p, s, nullptr, path);
     case 2:
       if (!planetile_ok(dtype, p)) return FMGAN_EUNSUPPORTED;
       return launch_planetile(input, kernel, out, p, s);
@@ -870,12 +862,13 @@ extern "C" int fmgan_upfirdn2d_strided(int dtype, const void* input, const void*
   }
 }
 
-extern "C" int fmgan_blur_noise_bias_act_f32(const float* input, const float* kernel, float* out, int batch,
-                                             int channels, int in_h, int in_w, long long in_plane_stride,
-                                             int in_row_stride, int kernel_h, int kernel_w, int pad_x0, int pad_x1,
-                                             int pad_y0, int pad_y1, const float* noise, const float* noise_weight,
-                                             const float* bias, int noise_batch, float alpha, float act_scale,
-                                             void* stream) {
+extern "C" int fmgan_blur_noise_bias_act_path_f32(const float* input, const float* kernel, float* out, int batch,
+                                                  int channels, int in_h, int in_w, long long in_plane_stride,
+                                                  int in_row_stride, int kernel_h, int kernel_w, int pad_x0, int pad_x1,
+                                                  int pad_y0, int pad_y1, const float* noise, const float* noise_weight,
+                                                  const float* bias, int noise_batch, float alpha, float act_scale,
+                                                  int force_path, void* stream) {
+  if (force_path != -1 && force_path != 1 && force_path != 4 && force_path != 5) return FMGAN_EUNSUPPORTED;
   if (batch < 0 || channels <= 0) return FMGAN_EINVAL;
   const long long major = (long long)batch * channels;
   if (major > 0x7fffffffLL) return FMGAN_EOVERFLOW;
@@ -892,7 +885,18 @@ extern "C" int fmgan_blur_noise_bias_act_f32(const float* input, const float* ke
   if (!rowmarch_ok(FMGAN_F32, p)) return FMGAN_EUNSUPPORTED;   // small planes: the caller keeps the two-pass form
   if ((long long)in_h * in_row_stride > 0x7fffffffLL) return FMGAN_EOVERFLOW;
   UfdEpilogue ep{noise, noise_weight, bias, channels, noise_batch, alpha, act_scale};
-  return launch_rowmarch(input, kernel, out, p, (hipStream_t)stream, &ep);
+  return launch_rowmarch(input, kernel, out, p, (hipStream_t)stream, &ep, force_path);
+}
+
+extern "C" int fmgan_blur_noise_bias_act_f32(const float* input, const float* kernel, float* out, int batch,
+                                             int channels, int in_h, int in_w, long long in_plane_stride,
+                                             int in_row_stride, int kernel_h, int kernel_w, int pad_x0, int pad_x1,
+                                             int pad_y0, int pad_y1, const float* noise, const float* noise_weight,
+                                             const float* bias, int noise_batch, float alpha, float act_scale,
+                                             void* stream) {
+  return fmgan_blur_noise_bias_act_path_f32(input, kernel, out, batch, channels, in_h, in_w, in_plane_stride,
+                                            in_row_stride, kernel_h, kernel_w, pad_x0, pad_x1, pad_y0, pad_y1, noise,
+                                            noise_weight, bias, noise_batch, alpha, act_scale, -1, stream);
 }
 
 extern "C" int fmgan_upfirdn2d(int dtype, const void* input, const void* kernel, void* out, int major, int in_h,

@@ -42,8 +42,11 @@ def lib():
     _sig(L.fmgan_upfirdn2d, [i, vp, vp, vp] + [i] * 15 + [vp])
     _sig(L.fmgan_upfirdn2d_strided, [i, vp, vp, vp] + [i] * 4 + [ll, i] + [i] * 11 + [vp])
     _sig(L.fmgan_blur_noise_bias_act_f32, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6 + [vp] * 3 + [i, f, f, vp])
+    _sig(L.fmgan_blur_noise_bias_act_path_f32, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6 + [vp] * 3 + [i, f, f, i, vp])
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
+    _sig(L.fmgan_fused_bias_act_bwd_blocks, [ll, i])
+    _sig(L.fmgan_fused_bias_act_bwd_f32, [vp] * 4 + [ll, i, f, f, vp])
     _sig(L.fmgan_prelu_backward_blocks, [ll, i])
     _sig(L.fmgan_prelu_backward_f32, [vp] * 5 + [ll, i, vp])
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
@@ -165,8 +168,10 @@ def upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
     return out
 
 
-def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_stride, kernel, pad_x0, pad_x1, pad_y0, pad_y1):
-    """up=down=1 FIR of a strided f32 input [major, in_h, in_w] (see aligned_rows_buffer) -> contiguous [major,out_h,out_w]."""
+def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_stride, kernel, pad_x0, pad_x1, pad_y0, pad_y1,
+                      force_path=-1):
+    """up=down=1 FIR of a strided f32 input [major, in_h, in_w] (see aligned_rows_buffer) -> contiguous [major,out_h,out_w].
+    force_path: -1 automatic; 4 = register row-march (path 1), 5 = LDS-DMA ring (path 1b) — A/B tests only."""
     k = kernel.contiguous()
     kh, kw = k.shape
     out_h, out_w = upfirdn2d_out_size(in_h, in_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1)
@@ -174,14 +179,14 @@ def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_strid
     with on_device(out) as stream:
         tok = _observer.begin('upfirdn2d', (major, in_h, in_w, out_h, out_w, 1, 1, 4))
         check(lib().fmgan_upfirdn2d_strided(F32, in_ptr, ptr(k), ptr(out), major, in_h, in_w, 1, plane_stride,
-                                            row_stride, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, -1, stream),
-              'upfirdn2d_strided')
+                                            row_stride, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, force_path,
+                                            stream), 'upfirdn2d_strided')
         _observer.end(tok)
     return out
 
 
 def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_stride, row_stride, kernel, pad, noise,
-                        noise_weight, bias, alpha, scale):
+                        noise_weight, bias, alpha, scale, force_path=-1):
     """blur -> (+noise) -> +bias -> lrelu*scale in one pass over a strided f32 input; returns [B,C,out_h,out_w] or None
     when the shape is not served by the row-march kernel (the caller then uses the two-pass form)."""
     k = kernel.contiguous()
@@ -194,10 +199,10 @@ def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_strid
     nz = noise.contiguous() if noise is not None else None
     with on_device(out) as stream:
         tok = _observer.begin('upfirdn2d', (batch * channels, in_h, in_w, out_h, out_w, 1, 1, 4))
-        st = lib().fmgan_blur_noise_bias_act_f32(in_ptr, ptr(k), ptr(out), batch, channels, in_h, in_w, plane_stride,
-                                                 row_stride, kh, kw, pad0, pad1, pad0, pad1, ptr(nz), ptr(noise_weight),
-                                                 ptr(bias), 1 if nz is None else nz.shape[0], float(alpha), float(scale),
-                                                 stream)
+        st = lib().fmgan_blur_noise_bias_act_path_f32(in_ptr, ptr(k), ptr(out), batch, channels, in_h, in_w,
+                                                      plane_stride, row_stride, kh, kw, pad0, pad1, pad0, pad1, ptr(nz),
+                                                      ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
+                                                      float(alpha), float(scale), force_path, stream)
         _observer.end(tok)
     if st == -2:
         return None
@@ -227,6 +232,33 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
                                          float(scale), stream), 'fused_bias_act')
         _observer.end(tok)
     return out
+
+
+def fused_bias_act_backward(grad_output, out, alpha, scale):
+    """grad_input of lrelu(x + b) * scale AND the bias gradient from ONE pass over the data: returns
+    (grad_input, grad_bias [C]) or None when the kernel does not serve the shape (not f32, < 3 dims, planes of fewer
+    than 64 or not a multiple of 4 elements) — the caller then runs fused_bias_act(..., 3, 1) and a torch sum."""
+    require_gpu(grad_output, 'input')
+    if grad_output.dtype != torch.float32 or grad_output.ndim < 3 or out.dtype != torch.float32:
+        return None
+    g = grad_output.contiguous()
+    r = out.contiguous()
+    b, c = g.shape[:2]
+    hw = g[0, 0].numel()
+    gx = lib().fmgan_fused_bias_act_bwd_blocks(b * c, hw)
+    if gx == 0 or r.numel() != g.numel():
+        return None
+    gi = torch.empty_like(g)
+    partial = torch.empty((b, c, gx), dtype=torch.float32, device=g.device)
+    with on_device(g) as stream:
+        tok = _observer.begin('fused_bias_act', (g.numel(), 4))
+        st = lib().fmgan_fused_bias_act_bwd_f32(ptr(g), ptr(r), ptr(gi), ptr(partial), b * c, hw, float(alpha),
+                                                float(scale), stream)
+        _observer.end(tok)
+    if st == -2:
+        return None
+    check(st, 'fused_bias_act_backward')
+    return gi, partial.sum((0, 2))
 
 
 def noise_bias_act(x, noise, noise_weight, bias, alpha, scale):

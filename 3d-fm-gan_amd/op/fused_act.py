@@ -34,6 +34,12 @@ class FusedLeakyReLUFunctionBackward(Function):
         ctx.save_for_backward(out)
         ctx.cfg = (negative_slope, scale)
         empty = grad_output.new_empty(0)
+        if bias:
+            # one pass: the kernel that writes grad_input also leaves per-block partial sums for the bias gradient
+            # (the reference: a full-size reduction kernel after the elementwise one, op/fused_act.py:42-50)
+            both = _native.fused_bias_act_backward(grad_output, out, negative_slope, scale)
+            if both is not None:
+                return both
         grad_input = fused.fused_bias_act(grad_output, empty, out, 3, 1, negative_slope, scale)
         grad_bias = grad_input.sum(_reduce_dims(grad_input)).detach() if bias else empty
         return grad_input, grad_bias

@@ -16,9 +16,13 @@ What is different, on purpose:
     all-reduce, as DataParallel's gather made it;
   * the generated image of the D step comes from the no_grad inference schedule (fused epilogues, side streams): its
     producers are frozen there (requires_grad(G, False), :453-457), so values are identical and no graph is kept;
-  * LPIPS / ArcFace / landmark / face-region terms need pretrained third-party networks that are not available
-    offline: `extra_losses` takes any such (weight, fn(output, reference) -> scalar) pairs; the shipped
-    configuration trains with the adversarial and L1 terms.
+  * the LPIPS and ArcFace terms (:529,:535) are computed when `lpips_model` / `face_rec_model` are passed, with the
+    reference's weights and arithmetic; their pretrained weights are not available offline, so
+    Module_Fix_Setup builds the two networks (lpips/, Util/arcface_pytorch/) with their own initialisation — the cost of
+    the iteration is that of the reference's, the loss VALUES are not.  The landmark heat-map and face-region terms
+    (:538-545) need the third-party `face_alignment` package (absent; both weights default to 0 in the reference's
+    reconstruction setting, train_3_encoder_hyperparams.py:66-68) and are not provided; `extra_losses` takes any
+    further (name, weight, fn(output, reference) -> scalar) terms.
 """
 import types
 
@@ -28,7 +32,8 @@ from torch import nn, optim
 
 from Miscellaneous import distributed as D_
 from Util.network_util import Forward_Inference_3_Encoder, MODULATION_ENCODING
-from Util.training_util import (L1_Loss, accumulate, d_logistic_loss, d_r1_loss, g_nonsaturating_loss, requires_grad)
+from Util.training_util import (Face_Identity_Loss, L1_Loss, LPIPS_Loss, accumulate, d_logistic_loss, d_r1_loss,
+                                g_nonsaturating_loss, requires_grad)
 
 
 def default_args(**over):
@@ -37,7 +42,8 @@ def default_args(**over):
         tsr_encode=MODULATION_ENCODING[0], w_plus_sliced_layer=None, use_tanh=False,
         tsr_train=True, w_train=True, w_plus_train=True,
         lr=0.001, rec_batch=16, r1=10, d_reg_every=16, use_g_reg=True, g_reg_every=4, generator_path_reg_weight=2,
-        path_reg_batch_shrink=2, l1_loss_lambda=3, grad_sync='ddp')
+        path_reg_batch_shrink=2, l1_loss_lambda=3, lpips_loss_lambda=3, ep_lpips_l1_weight_shrink=10,
+        face_id_loss_lambda=30, face_id_loss_type='MSE', grad_sync='ddp')
     for k, v in over.items():
         setattr(a, k, v)
     return a
@@ -55,6 +61,23 @@ def _sync_grads(args, nets):
         return
     params = [p for n in nets for p in n.parameters() if p.requires_grad]
     D_.gather_grad(params, algorithm=getattr(args, 'grad_algorithm', 'reduce_scatter'))
+
+
+def Module_Fix_Setup(args, device):
+    """The frozen loss networks of train_3_encoder.py:366-396 that can be built offline: LPIPS (net-lin / VGG16) and the
+    ArcFace identity network (resnet_face18, use_se=False), eval mode, no parameter gradients.  Returns
+    (lpips_model, face_rec_model).  The VGG trunk runs channels_last: MIOpen's fp32 implicit-GEMM kernels are NHWC-native
+    (same finding as for the pSp encoder)."""
+    import lpips
+    from Util.arcface_pytorch.resnet_face_recognition import resnet_face18
+    lpips_model = lpips.PerceptualLoss(model='net-lin', net='vgg').to(device)
+    face_rec_model = resnet_face18(use_se=False).to(device)
+    requires_grad(face_rec_model, False)
+    face_rec_model.eval()
+    if torch.device(device).type == 'cuda' and getattr(args, 'loss_nets_channels_last', True):
+        lpips_model = lpips_model.to(memory_format=torch.channels_last)
+        face_rec_model = face_rec_model.to(memory_format=torch.channels_last)
+    return lpips_model, face_rec_model
 
 
 def Optimizer_Initilization(args, G, E_Tsr, E_W, E_W_Plus, D, D_edit=None, ckpt=None):
@@ -135,8 +158,10 @@ def _trained(args, G, E_Tsr, E_W, E_W_Plus):
 
 
 def G_Loss_BackProp(G, E_Tsr, E_W, E_W_Plus, D, g_input, r_input, g_ref, args, loss_dict, g_enc_optim,
-                    extra_losses=()):
-    """Update G and the encoders on the adversarial + reconstruction losses (train_3_encoder.py:495-558)."""
+                    lpips_model=None, face_rec_model=None, fa_model=None, iter_idx=0, extreme_ds_flag=False,
+                    ds_flag=False, extra_losses=()):
+    """Update G and the encoders on the adversarial + reconstruction losses (train_3_encoder.py:495-558; the
+    reference's argument order).  lpips_model / face_rec_model = None leaves that term out."""
     requires_grad(G, True)
     requires_grad(E_Tsr, args.tsr_train)
     requires_grad(E_W, args.w_train)
@@ -147,9 +172,18 @@ def G_Loss_BackProp(G, E_Tsr, E_W, E_W_Plus, D, g_input, r_input, g_ref, args, l
     out_pred = _local(D)(g_output)            # D is frozen here: nothing of it to synchronise
     g_loss = g_nonsaturating_loss(out_pred)
     loss_dict['g'] = g_loss
-    l1_loss = args.l1_loss_lambda * L1_Loss(g_output, g_ref)
+    shrink = args.ep_lpips_l1_weight_shrink if extreme_ds_flag else 1        # :517-519
+    face_id_reference = g_input if extreme_ds_flag else g_ref
+    l1_loss = args.l1_loss_lambda / shrink * L1_Loss(g_output, g_ref)
     loss_dict['l1'] = l1_loss
     total_loss = g_loss + l1_loss
+    if lpips_model is not None:
+        loss_dict['lpips'] = args.lpips_loss_lambda / shrink * LPIPS_Loss(g_output, g_ref, lpips_model)
+        total_loss = total_loss + loss_dict['lpips']
+    if face_rec_model is not None:
+        loss_dict['face_id'] = args.face_id_loss_lambda * Face_Identity_Loss(g_output, face_id_reference, face_rec_model,
+                                                                              args.face_id_loss_type)
+        total_loss = total_loss + loss_dict['face_id']
     for name, weight, fn in extra_losses:
         loss_dict[name] = weight * fn(g_output, g_ref)
         total_loss = total_loss + loss_dict[name]
@@ -206,15 +240,20 @@ class Trainer:
     nets: dict with G, E_Tsr, E_W, E_W_Plus, D (bare modules on this rank's device; BatchNorm of the encoders in eval
     mode).  grad_sync: 'ddp' wraps them in DistributedDataParallel, 'flat' in Replica + gather_grad."""
 
-    def __init__(self, nets, args, device=None, g_ema=None):
+    def __init__(self, nets, args, device=None, g_ema=None, lpips_model=None, face_rec_model=None):
         import copy
         self.args = args
+        self.lpips_model, self.face_rec_model = lpips_model, face_rec_model
         ddp = getattr(args, 'grad_sync', 'ddp') == 'ddp'
         self.bare = dict(nets)
         self.g_ema = g_ema if g_ema is not None else copy.deepcopy(nets['G']).eval().requires_grad_(False)
         for m in nets.values():
             m.requires_grad_(True)
-        self.nets = {k: D_.data_parallel(m, device, overlap=ddp) for k, m in nets.items()}
+        # unused parameters exist in G (mapping network, constant input) and — when only some W+ columns are
+        # co-modulated — in the pSp encoder's style heads of the other columns
+        unused = {'G': True, 'E_W_Plus': args.w_plus_sliced_layer is not None}
+        self.nets = {k: D_.data_parallel(m, device, overlap=ddp, find_unused_parameters=unused.get(k, False))
+                     for k, m in nets.items()}
         self.g_enc_optim, self.d_optim, _ = Optimizer_Initilization(
             args, self.bare['G'], self.bare['E_Tsr'], self.bare['E_W'], self.bare['E_W_Plus'], self.bare['D'])
         self.accum = 0.5 ** (32 / (10 * 1000))
@@ -229,7 +268,8 @@ class Trainer:
         D_Loss_BackProp(G, E_Tsr, E_W, E_W_Plus, Dn, g_input, r_input, g_ref, a, ld, self.d_optim)
         if self.iter_idx % a.d_reg_every == 0:
             ld['r1'] = D_Reg_BackProp(g_ref, Dn, a, self.d_optim)
-        G_Loss_BackProp(G, E_Tsr, E_W, E_W_Plus, Dn, g_input, r_input, g_ref, a, ld, self.g_enc_optim)
+        G_Loss_BackProp(G, E_Tsr, E_W, E_W_Plus, Dn, g_input, r_input, g_ref, a, ld, self.g_enc_optim,
+                        self.lpips_model, self.face_rec_model, None, self.iter_idx)
         if self.iter_idx % a.g_reg_every == 0 and a.use_g_reg:
             ld['g_reg'], _, self.mean_path_length = G_Reg_BackProp(G, E_Tsr, E_W, E_W_Plus, g_input, r_input, a,
                                                                    self.mean_path_length, self.g_enc_optim, ppl_choice)

@@ -49,7 +49,18 @@ WORKLOADS = {
     # R1 every 16, G non-saturating + L1, path length every 4 on batch/2, EMA; Adam on G+encoders and on D.
     'trainstep256': dict(size=256, batch=16, desc='train() iteration @256^2, fp32, B=16/GPU: D loss + R1/16 + G adv+L1 + '
                          'path length/4 on B/2 + EMA, Adam; DDP/RCCL all-reduce of G/encoder and D gradients when N>1'),
+    # BASELINE config 5: the train() iteration at 1024^2 — Generator(1024), Discriminator(1024), 18 styles —
+    # with the LPIPS (net-lin VGG16) and ArcFace (resnet_face18) loss networks in the G step at the reference's weights
+    # (lpips_loss_lambda=3, face_id_loss_lambda=30, train_3_encoder_hyperparams.py:62,65).  Their pretrained weights are
+    # not available offline: both are built with their own initialisation and are LOAD GENERATORS, not parity rows.
+    'trainstep1024': dict(size=1024, batch=8, loss_nets=True,
+                          desc='cfg5: train() iteration @1024^2, fp32, B=8/GPU: D(1024) loss + R1/16 + G adv + L1 + LPIPS('
+                          'VGG16 topology, random init: load only) + ArcFace(resnet_face18 topology, random init: load only) '
+                          '+ path length/4 on B/2 + EMA, Adam; DDP/RCCL all-reduce when N>1'),
 }
+# the lazy regularisers recur every 16 (R1) and 4 (path length) iterations: any 16 consecutive iterations hold exactly
+# one R1 step and four path-length steps, so a timed window of 16 IS the amortised cost of an iteration
+TRAINSTEP_WINDOW = 16
 
 
 _T0 = time.time()
@@ -146,18 +157,19 @@ def make_train_step(nets, batch, device, rank, world):
     return step, (photo, render)
 
 
-def make_trainstep(nets, batch, device, rank, world, size):
+def make_trainstep(nets, batch, device, rank, world, size, loss_nets=False):
     """A full training iteration (3d-fm-gan_amd/train_3_encoder.py::Trainer.step) on synthetic pairs."""
     import stylegan2
     import train_3_encoder as T
     torch.manual_seed(1)
     d = stylegan2.Discriminator(size).to(device)
+    lp, fr = T.Module_Fix_Setup(T.default_args(), device) if loss_nets else (None, None)
     gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
     photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
     render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
     ref = (torch.rand(batch, 3, size, size, generator=gen) * 2 - 1).to(device)
     tr = T.Trainer(dict(G=nets['g'], E_Tsr=nets['e_tsr'], E_W=nets['e_w'], E_W_Plus=nets['e_wp'], D=d),
-                   T.default_args(rec_batch=batch), device)
+                   T.default_args(rec_batch=batch), device, lpips_model=lp, face_rec_model=fr)
 
     def step():
         tr.step(photo, render, ref)
@@ -184,7 +196,7 @@ def train_leg(name, steps, world, timeout_s):
     import subprocess
     env = dict(os.environ)
     if world > 1:
-        env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + (7 if name == 'train256' else 13))
+        env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + {'train256': 7, 'trainstep256': 13}.get(name, 19))
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--workload', name, '--steps', str(steps),
            '--warmup', '2', '--no-cpu-baseline']
     log(f'{name}: child process, time box {timeout_s:.0f} s')
@@ -479,12 +491,23 @@ def main():
         else:
             for m in nets.values():
                 m.requires_grad_(True)
-            step, _ = make_trainstep(nets, batch, device, rank, world, wl['size'])
+            step, trainer = make_trainstep(nets, batch, device, rank, world, wl['size'], wl.get('loss_nets', False))
         for i in range(args.warmup):
             step()
             torch.cuda.synchronize()
             log(f'{args.workload}: warm-up step {i + 1}/{args.warmup} done')
+        it0 = trainer.iter_idx if args.workload.startswith('trainstep') else 0
         dt = timed(step, args.steps, 0, world)
+        mix = None
+        if args.workload.startswith('trainstep'):
+            a = trainer.args
+            its = range(it0, it0 + args.steps)
+            mix = {'iterations': f'{it0}..{it0 + args.steps - 1}', 'd_steps': args.steps, 'g_steps': args.steps,
+                   'r1_steps': sum(1 for i in its if i % a.d_reg_every == 0),
+                   'path_length_steps': sum(1 for i in its if i % a.g_reg_every == 0),
+                   'amortised': args.steps % TRAINSTEP_WINDOW == 0}
+            torch.cuda.synchronize()
+            mix['peak_hbm_gb'] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
         if rank == 0:
             print(json.dumps({
                 'metric': '(photo,render) pairs/sec (forward+backward)' if args.workload == 'train256' else
@@ -494,7 +517,7 @@ def main():
                 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
                            'image_size': wl['size'], 'parallelism': f'dp{world} (DDP, 256 MiB buckets)' if world > 1 else 'single GPU',
-                           **dist_info(world)}}))
+                           'phase_mix': mix, **dist_info(world)}}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -633,13 +656,16 @@ def main():
             # running this script with --workload: MIOpen has no pre-built kernels for gfx950 in this image and compiles
             # every backward convolution on first use — minutes on a fresh box (seconds once its cache is warm, see
             # warm_miopen_cache) — so the legs run inside a time box and the headline line is never held hostage by them.
-            t_steps = max(3, args.steps // 4)
-            for name in ('train256', 'trainstep256'):
+            for name in ('train256', 'trainstep256', 'trainstep1024'):
+                # a training iteration is timed over whole windows of 16 (one R1 step + four path-length steps each)
+                t_steps = TRAINSTEP_WINDOW if name.startswith('trainstep') else max(3, args.steps // 4)
                 rec = train_leg(name, t_steps, world, float(os.environ.get('FMGAN_BENCH_TRAIN_TIMEOUT', '480')))
                 if 'value' in rec:
                     out[name + '_pairs_per_s'] = rec['value']
                     out[name + '_ms_per_step'] = rec['ms_per_step']
                     out['config'][name] = f"{WORKLOADS[name]['desc']} ({t_steps} timed steps, child process)"
+                    if rec['config'].get('phase_mix'):
+                        out['config'][name + '_phase_mix'] = rec['config']['phase_mix']
                 else:
                     out[name + '_pairs_per_s'] = None
                     out['config'][name] = rec['skipped']

@@ -117,6 +117,16 @@ int fmgan_blur_noise_bias_act_f32(const float *input, const float *kernel, float
                                   int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                   const float *noise, const float *noise_weight, const float *bias,
                                   int noise_batch, float alpha, float act_scale, void *stream);
+/* The same with the row-march variant chosen by the caller (tests, measurements): force_path -1 / 1 automatic,
+ * 4 = register row-march (path 1), 5 = LDS-DMA ring (path 1b; FMGAN_EUNSUPPORTED when its alignment rules do not hold).
+ * Both variants produce the same bits.  fmgan_upfirdn2d(_strided) accept the same two values. */
+int fmgan_blur_noise_bias_act_path_f32(const float *input, const float *kernel, float *out,
+                                       int batch, int channels, int in_h, int in_w,
+                                       long long in_plane_stride, int in_row_stride,
+                                       int kernel_h, int kernel_w,
+                                       int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                       const float *noise, const float *noise_weight, const float *bias,
+                                       int noise_batch, float alpha, float act_scale, int force_path, void *stream);
 
 /*
  * fused_bias_act: out[i] = act'(x[i] + bias[(i / step_b) % size_b]; refer[i]) * scale
@@ -140,6 +150,19 @@ int fmgan_noise_bias_act_f32(const float *x, const float *noise, const float *no
                              const float *bias, float *out,
                              int batch, int channel, int hw, int noise_batch,
                              float alpha, float scale, void *stream);
+
+/*
+ * FusedLeakyReLUFunctionBackward in one pass (op/fused_act.py:29-50: fused_bias_act(grad_output, empty, out, 3, 1, ...)
+ * followed by grad_input.sum over batch and space for the bias):
+ *   grad_in[p,i] = (ref_out[p,i] > 0 ? grad_out[p,i] : alpha * grad_out[p,i]) * scale     (bits of fmgan_fused_bias_act 3/1)
+ *   partial[p, blk] = sum of the block's share of grad_in[p, :]
+ * over `planes` = batch*channels contiguous planes of `hw` f32 elements; partial [planes, fmgan_fused_bias_act_bwd_blocks]
+ * — the caller sums it to [channels] (deterministic).  hw % 4 == 0, hw >= 64 and 16-byte aligned pointers, else
+ * FMGAN_EUNSUPPORTED (fmgan_fused_bias_act_bwd_blocks returns 0): the caller then uses fmgan_fused_bias_act + a sum.
+ */
+int fmgan_fused_bias_act_bwd_blocks(long long planes, int hw);
+int fmgan_fused_bias_act_bwd_f32(const float *grad_out, const float *ref_out, float *grad_in, float *partial,
+                                 long long planes, int hw, float alpha, float scale, void *stream);
 
 /*
  * Backward of PReLU(channels) on channels-innermost activations (the pSp encoder's units,

@@ -146,6 +146,11 @@ def grad_sample(t):
 # One training iteration's four gradient computations (train_3_encoder.py:448-596) at a size the CPU reference
 # finishes in a minute: Generator(64) + Discriminator(64), encoders on 256^2 (they are shape-locked to it).
 TRAIN_STEP_CASE = dict(name='train_64', size=64, b=4, ppl_idx=[0, 2])
+# BASELINE config 5's networks (Generator(1024) + Discriminator(1024), 18 styles) at the batch the CPU reference still
+# finishes in minutes, fp32 and fp64; path length on one sample (batch / path_reg_batch_shrink).
+TRAIN_STEP_1024_CASE = dict(name='train_1024', size=1024, b=2, ppl_idx=[1])
+# identity term of the G step: ArcFace features of grey, pooled images and the two loss forms (training_util.py:148-205)
+FACE_ID_CASE = dict(name='face_id', b=2, size=256)
 # train_3_encoder_hyperparams.py:53-63
 TRAIN_HP = dict(lr=0.001, r1=10, d_reg_every=16, g_reg_every=4, path_reg_weight=2, path_reg_batch_shrink=2,
                 l1_loss_lambda=3)

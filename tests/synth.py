@@ -50,6 +50,12 @@ def _rule(kind, key, ref):
         if leaf == 'bias':
             return ('normal', 0.1, 0.0)
         return ('normal', 1.0, 0.0)            # equalised-lr weights are N(0,1); the scale is applied in forward
+    if kind == 'arcface':                      # ResNetFace: convs, one fc, BatchNorm, scalar PReLU slopes
+        if ref.ndim in (2, 4):
+            return ('normal', (1.0 / ref[0].numel()) ** 0.5, 0.0)
+        if 'prelu' in key:
+            return ('normal', 0.05, 0.25)
+        return ('normal', 0.1, 0.0) if leaf == 'bias' else ('normal', 0.1, 1.0)
     # encoders: plain nn.Conv2d / BatchNorm2d / PReLU / EqualLinear
     if ref.ndim == 4:
         fan_in = shape[1] * shape[2] * shape[3]

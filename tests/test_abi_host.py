@@ -88,6 +88,23 @@ def test_prelu_backward_host_logic():
     assert L.fmgan_prelu_backward_f32(None, None, None, None, None, -1, 64, None) == -1
 
 
+def test_fused_bias_act_backward_host_logic():
+    """fmgan_fused_bias_act_bwd_blocks / _f32: which planes the one-pass backward serves, partial columns per plane,
+    argument checks — all before any HIP call."""
+    L = _lib()
+    L.fmgan_fused_bias_act_bwd_blocks.argtypes = [ctypes.c_longlong, ctypes.c_int]
+    for planes, hw, want in ((0, 64, 0), (8, 16, 0), (8, 63, 0), (8, 66, 0), (8, 64, 1), (8, 4096, 1), (8, 4100, 2),
+                             (256, 1024 * 1024, 64), (1 << 31, 64, 0)):
+        assert L.fmgan_fused_bias_act_bwd_blocks(planes, hw) == want, (planes, hw)
+    L.fmgan_fused_bias_act_bwd_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_float, ctypes.c_void_p]
+    assert L.fmgan_fused_bias_act_bwd_f32(None, None, None, None, 0, 64, 0.2, 1.4, None) == 0       # empty
+    assert L.fmgan_fused_bias_act_bwd_f32(None, None, None, None, 4, 64, 0.2, 1.4, None) == -1      # null pointers
+    assert L.fmgan_fused_bias_act_bwd_f32(None, None, None, None, -1, 64, 0.2, 1.4, None) == -1
+    assert L.fmgan_fused_bias_act_bwd_f32(16, 16, 16, 16, 4, 30, 0.2, 1.4, None) == -2              # unserved plane size
+    assert L.fmgan_fused_bias_act_bwd_f32(20, 16, 16, 16, 4, 64, 0.2, 1.4, None) == -2              # misaligned
+
+
 def test_product_has_no_cpu_path():
     from op import upfirdn2d, fused_leaky_relu, FusedLeakyReLU
     x = torch.randn(1, 2, 8, 8)

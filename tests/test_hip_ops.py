@@ -145,8 +145,12 @@ def test_blur_with_fused_epilogue_matches_two_passes(cfg):
     (1, 1, 40, 1027, (3, 2), ('rand', 3, 4, 9), 1),# 3-row kernel, pad0 = 3, out 1029 - not a multiple of 4 -> path 1 on both sides
     (1, 2, 36, 1029, (3, 2), ('rand', 4, 3, 11), 1),  # out 1032 x 38, 3-column kernel
     (2, 2, 1025, 1025, (1, 1), 'blur4', 1),        # the headline geometry, 4 planes
+    # production tile heights (the cases above get 8-row tiles: 11 steps, the steady-state loop's back-edge is never
+    # taken): 512 planes of [257, 1025] -> 64-row tiles (67 steps), per-sample noise; 256 planes -> 32-row tiles
+    (16, 32, 257, 1025, (1, 1), 'blur4', 16),
+    (8, 32, 257, 1025, (1, 1), 'blur4', 1),
 ])
-def test_dma_ring_blur_equals_register_row_march(cfg, monkeypatch):
+def test_dma_ring_blur_equals_register_row_march(cfg):
     """upfirdn2d.hip path 1b (LDS-DMA ring, hand-counted s_waitcnt) against path 1 (register staging) on the same
     aligned-row buffer: bit-identical, plain and with the fused noise/bias/lrelu store; NaN padding must not leak."""
     from op import _native
@@ -164,11 +168,14 @@ def test_dma_ring_blur_equals_register_row_march(cfg, monkeypatch):
     off = pad[0] % 4
     buf[:, :, off:off + w] = x
     res = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('FMGAN_UFD_DMA', mode)
-        plain = _native.upfirdn2d_strided(p0, dev(), b * c, h, w, ps, rs, k, pad[0], pad[1], pad[0], pad[1])
-        fused = _native.blur_noise_bias_act(p0, dev(), b, c, h, w, ps, rs, k, pad, nz, nw, bias, 0.2, 2 ** 0.5)
+    ring_ok = ow % 4 == 0      # path 1b needs 16-byte output rows; otherwise both sides are path 1 (kept as a case)
+    for mode, path in (('0', 4), ('1', 5 if ring_ok else -1)):
+        plain = _native.upfirdn2d_strided(p0, dev(), b * c, h, w, ps, rs, k, pad[0], pad[1], pad[0], pad[1], force_path=path)
+        fused = _native.blur_noise_bias_act(p0, dev(), b, c, h, w, ps, rs, k, pad, nz, nw, bias, 0.2, 2 ** 0.5,
+                                            force_path=path)
         res[mode] = (plain, fused)
+    auto = _native.blur_noise_bias_act(p0, dev(), b, c, h, w, ps, rs, k, pad, nz, nw, bias, 0.2, 2 ** 0.5)
+    assert torch.equal(auto, res['1'][1])
     assert res['0'][0].shape[-2:] == (oh, ow)
     assert torch.equal(res['0'][0], res['1'][0])
     assert res['0'][1] is not None and torch.equal(res['0'][1], res['1'][1])
@@ -312,6 +319,53 @@ def test_fused_act_full_size_bit_exact():
     gi = _native.fused_bias_act(torch.ones_like(x), e, y, 3, 1, 0.2, 2 ** 0.5)
     expect = torch.where(y > 0, torch.tensor(2 ** 0.5, device=d), torch.tensor(0.2 * 2 ** 0.5, device=d))
     torch.testing.assert_close(gi, expect, atol=0, rtol=0)
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 8, 8), (3, 5, 16, 20), (2, 32, 64, 64), (4, 16, 256, 256), (1, 3, 1024, 1024),
+                                   (2, 3, 8, 8, 4)])
+def test_fused_act_backward_with_bias_partials(shape):
+    """One-pass backward (grad_input + per-block partial sums of it): grad_input has the bits of the reference form
+    fused_bias_act(g, empty, out, 3, 1) — i.e. of the C oracle — and the bias gradient equals the float64 plane sums of
+    that grad_input to fp32 summation accuracy (the reference: a float32 torch .sum of the same values)."""
+    from op import _native
+    from oracle import c_oracle
+    g = synth.tensor(f'fbb/{shape}/g', shape)
+    out = synth.tensor(f'fbb/{shape}/o', shape)
+    out.view(-1)[::5] = 0.0          # `ref > 0` is strict (fused_bias_act_kernel.cu:42)
+    both = _native.fused_bias_act_backward(g.to(dev()), out.to(dev()), 0.2, 2 ** 0.5)
+    assert both is not None, 'shape should be served by the one-pass kernel'
+    gi, gb = both
+    ref = c_oracle.fused_bias_act(g.numpy(), None, out.numpy(), 3, 1, 0.2, 2 ** 0.5)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ref)
+    dims = tuple([0] + list(range(2, len(shape))))
+    exact = ref.astype(np.float64).sum(axis=dims)
+    mag = np.abs(ref).astype(np.float64).sum(axis=dims)
+    np.testing.assert_allclose(gb.cpu().numpy(), exact, atol=float(2e-6 * mag.max()), rtol=0)
+    # and it is what autograd uses: same bits as the function's grad_bias, run twice (bit-reproducible)
+    from op import fused_leaky_relu
+    x = synth.tensor(f'fbb/{shape}/x', shape).to(dev()).requires_grad_(True)
+    b = synth.tensor(f'fbb/{shape}/b', (shape[1],)).to(dev()).requires_grad_(True)
+    go = g.to(dev())
+    g1 = torch.autograd.grad(fused_leaky_relu(x, b), [x, b], go)
+    g2 = torch.autograd.grad(fused_leaky_relu(x, b), [x, b], go)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    y = fused_leaky_relu(x, b).detach()
+    e = go.new_empty(0)
+    two_pass = _native.fused_bias_act(go, e, y, 3, 1, 0.2, 2 ** 0.5)
+    assert torch.equal(g1[0], two_pass)
+    torch.testing.assert_close(g1[1], two_pass.double().sum(dims).float(), atol=float(2e-6 * two_pass.abs().double().sum(dims).max()), rtol=0)
+
+
+def test_fused_act_backward_falls_back_for_unserved_shapes():
+    """2-D activations (the mapping network) and tiny / odd planes keep the two-step form."""
+    from op import _native, fused_leaky_relu
+    for shape in ((4, 512), (2, 6, 4, 4), (3, 5, 7, 3)):
+        g = synth.tensor(f'fbf/{shape}/g', shape).to(dev())
+        assert _native.fused_bias_act_backward(g, g, 0.2, 2 ** 0.5) is None
+        x = g.clone().requires_grad_(True)
+        b = synth.tensor(f'fbf/{shape}/b', (shape[1],)).to(dev()).requires_grad_(True)
+        gx, gb = torch.autograd.grad(fused_leaky_relu(x, b), [x, b], g)
+        torch.testing.assert_close(gb, gx.sum([0] + list(range(2, len(shape)))))
 
 
 def test_noise_bias_act_matches_unfused_bitwise():

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 3): the FMGAN_UFD_DMA environment switch this script drives was removed from the library; it documents how
+# the round-2 numbers in profiles/r02_blur_probe.md were taken (tree ab53d56).  A/B now: force_path 4 / 5 through the ABI.
 # In-step A/B of the headline blur's launch modes (FMGAN_UFD_DMA): bench.py's roofline object + FETCH_SIZE per launch.
 # usage (GPU box): bash tools/exp/ab_dma.sh "1 0" [reps]
 # NOTE: the in-step timing of this kernel is BIMODAL between consecutive process launches (4.65 vs 5.1 TB/s on one box,

@@ -350,7 +350,36 @@ class _FixedProbe:
         torch.randn_like = self.orig
 
 
-def gen_train_step():
+def gen_face_id():
+    """The identity term of the G step with the reference's ArcFace topology (Util/arcface_pytorch/
+    resnet_face_recognition.py:170-238, resnet_face18(use_se=False)) and its wrappers (Util/training_util.py:131-205):
+    features of the converted image, both loss forms, and the gradient of the MSE form w.r.t. the output image."""
+    from Util.arcface_pytorch.resnet_face_recognition import resnet_face18
+    c = cases.FACE_ID_CASE
+    out = {}
+    m = resnet_face18(use_se=False)
+    sd = synth.state_dict('arcface', m.state_dict(), seed=9)
+    m.load_state_dict(sd)
+    m.eval().requires_grad_(False)
+    json.dump(synth.manifest(sd), open(os.path.join(OUT, 'arcface_manifest.json'), 'w'), indent=0, sort_keys=True)
+    a = synth.tensor(c['name'] + '/a', (c['b'], 3, c['size'], c['size']), dist='uniform').requires_grad_(True)
+    b = synth.tensor(c['name'] + '/b', (c['b'], 3, c['size'], c['size']), dist='uniform')
+    conv = ref_training_util.Convert_Tensor_For_Face_Recognition_Loss(a)
+    out['converted'] = npy(conv)
+    out['features'] = npy(m(conv))
+    mse = ref_training_util.Face_Identity_Loss(a, b, m, 'MSE')
+    cos = ref_training_util.Face_Identity_Loss(a, b, m, 'CosineSimilarity')
+    ga, = torch.autograd.grad(mse, a)
+    out['mse'], out['cos'] = np.float64(mse.item()), np.float64(cos.item())
+    out['grad_a/sub'] = subsample(ga, 8)
+    # LPIPS_Loss is a batch mean over whatever module it is given (the reference's lpips package itself cannot be
+    # imported offline: torchvision / skimage / IPython): pinned with a stand-in distance
+    out['lpips_wrapper'] = np.float64(ref_training_util.LPIPS_Loss(a, b, lambda x, y: (x - y).abs().mean([1, 2, 3])).item())
+    np.savez_compressed(os.path.join(OUT, 'face_id.npz'), **out)
+    print('face_id', len(out), mse.item(), cos.item())
+
+
+def gen_train_step(c=None, fname='train_step.npz'):
     """The four gradient computations of one training iteration (train_3_encoder.py:448-596) with the reference's
     modules and the reference's own loss functions (Util/training_util.py), all evaluated at the same weights:
       d:   D_Loss_BackProp   d_logistic_loss(D(ref), D(fake)),  fake from frozen G/encoders           (:448-477)
@@ -359,7 +388,7 @@ def gen_train_step():
            need pretrained third-party weights that are not available offline)             (:495-558)
       ppl: G_Reg_BackProp    path-length penalty on batch/2 through PPL_regularize=True               (:561-596)
     Stored: the loss values and a strided sample + norm of every parameter gradient, fp32 and fp64."""
-    c = cases.TRAIN_STEP_CASE
+    c = c or cases.TRAIN_STEP_CASE
     hp = cases.TRAIN_HP
     out = {}
     size, b = c['size'], c['b']
@@ -434,17 +463,24 @@ def gen_train_step():
         out['ppl/lengths' + sfx] = npy(path_lengths)
         for k, m in ge.items():
             _sample_grads(out, 'ppl/' + k, m.named_parameters(), sfx)
-        print('  train_step', dt, d_loss.item(), r1.item(), g_loss.item(), l1.item(), path_loss.item())
-    np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **out)
-    print('train_step', len(out))
+        print('  train_step', c['name'], dt, d_loss.item(), r1.item(), g_loss.item(), l1.item(), path_loss.item(), flush=True)
+        del fake, out_pred, ref_pred, d_loss, real, real_pred, r1, g_loss, l1, img, path_lengths, weighted
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, len(out))
+
+
+def gen_train_step_1024():
+    """The same four computations at BASELINE config 5's sizes: Generator(1024), Discriminator(1024), 18 styles, B=2."""
+    gen_train_step(cases.TRAIN_STEP_1024_CASE, 'train_step_1024.npz')
 
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     which = sys.argv[1:] or ['upfirdn2d', 'fused_act', 'modules', 'generator', 'e2e', 'discriminator', 'image_io',
-                             'e2e_grad', 'fp64', 'train_step']
+                             'e2e_grad', 'fp64', 'train_step', 'face_id', 'train_step_1024']
     for w in which:
         {'upfirdn2d': gen_upfirdn2d, 'fused_act': gen_fused_act, 'modules': gen_modules,
          'generator': gen_generator, 'e2e': gen_encoders_e2e, 'discriminator': gen_discriminator,
-         'image_io': gen_image_io, 'e2e_grad': gen_e2e_grad, 'fp64': gen_fp64, 'train_step': gen_train_step}[w]()
+         'image_io': gen_image_io, 'e2e_grad': gen_e2e_grad, 'fp64': gen_fp64, 'train_step': gen_train_step,
+         'train_step_1024': gen_train_step_1024, 'face_id': gen_face_id}[w]()
