@@ -510,8 +510,14 @@ __global__ __launch_bounds__(256) void ufd_dmaring_f32(const DRParams p) {
 // so the copy is one flat coalesced stream) in LDS and each thread filters consecutive outputs from there.
 struct PTParams {
   int planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, kh, kw, pb;
+  long long in_plane_stride; int in_row_stride;      // elements; contiguous planes: in_h*in_w and in_w
+  // optional StyledConv epilogue in the store (EPI): lrelu((y + nw*noise) + bias[c]) * scale, the roundings of
+  // fmgan_noise_bias_act_f32 — the 4^2..32^2 upsampling layers then need one launch instead of blur + epilogue
+  const float* noise; const float* noise_weight; const float* bias;
+  int channels, noise_batch; float alpha, act_scale;
 };
 
+template <bool EPI>
 __global__ __launch_bounds__(256) void ufd_planetile_f32(const float* __restrict__ in, const float* __restrict__ kern,
                                                          float* __restrict__ out, const PTParams p) {
   extern __shared__ float tile[];
@@ -524,10 +530,19 @@ __global__ __launch_bounds__(256) void ufd_planetile_f32(const float* __restrict
   const int plane0 = blockIdx.x * p.pb;
   const int np = min(p.pb, p.planes - plane0);
   const int in_sz = p.in_h * p.in_w, out_sz = p.out_h * p.out_w;
-  const float* src = in + (long long)plane0 * in_sz;
-  for (int i = threadIdx.x; i < np * in_sz; i += 256) tile[i] = src[i];
+  const float* src = in + (long long)plane0 * p.in_plane_stride;
+  if (p.in_row_stride == p.in_w && p.in_plane_stride == in_sz) {
+    for (int i = threadIdx.x; i < np * in_sz; i += 256) tile[i] = src[i];
+  } else {                                   // aligned-row layout of the transposed conv's private intermediate
+    for (int i = threadIdx.x; i < np * in_sz; i += 256) {
+      const int pl = i / in_sz, r = i - pl * in_sz;
+      const int y = r / p.in_w, x = r - y * p.in_w;
+      tile[i] = src[(long long)pl * p.in_plane_stride + y * p.in_row_stride + x];
+    }
+  }
   __syncthreads();
   float* dst = out + (long long)plane0 * out_sz;
+  const float nw = (EPI && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
   for (int o = threadIdx.x; o < np * out_sz; o += 256) {
     const int pl = o / out_sz, r = o - pl * out_sz;
     const int oy = r / p.out_w, ox = r - oy * p.out_w;
@@ -543,6 +558,14 @@ __global__ __launch_bounds__(256) void ufd_planetile_f32(const float* __restrict
         const float x = (yok && ix >= 0 && ix < p.in_w) ? tp[iy * p.in_w + ix] : 0.f;
         v = fmaf(x, kf[ky][kx], v);
       }
+    }
+    if constexpr (EPI) {
+      const int plane = plane0 + pl;
+      const int c = plane % p.channels, b = plane / p.channels;
+      const float n = p.noise ? p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * out_sz + r] : 0.f;
+      const float bv = p.bias ? p.bias[c] : 0.f;
+      const float t = __fadd_rn(__fadd_rn(v, __fmul_rn(nw, n)), bv);
+      v = __fmul_rn(t > 0.f ? t : __fmul_rn(t, p.alpha), p.act_scale);
     }
     dst[o] = v;
   }
@@ -740,11 +763,17 @@ int launch_rowmarch(const void* in, const void* kern, void* out, const UfdParams
 bool planetile_ok(int dtype, const UfdParams& p) {
   return dtype == FMGAN_F32 && p.minor == 1 && p.up_x == 1 && p.up_y == 1 && p.down_x == 1 && p.down_y == 1 &&
          p.kh <= 4 && p.kw <= 4 && (long long)p.in_h * p.in_w <= 12288 && (long long)p.out_h * p.out_w <= (1 << 20) &&
-         p.in_row_stride == p.in_w && p.in_plane_stride == (long long)p.in_h * p.in_w;
+         (long long)p.in_h * p.in_row_stride <= 0x7fffffffLL;
 }
 
-int launch_planetile(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s) {
+int launch_planetile(const void* in, const void* kern, void* out, const UfdParams& p, hipStream_t s,
+                     const UfdEpilogue* ep = nullptr) {
   PTParams t{p.major, p.in_h, p.in_w, p.out_h, p.out_w, p.pad_x0, p.pad_y0, p.kh, p.kw, 1};
+  t.in_plane_stride = p.in_plane_stride; t.in_row_stride = p.in_row_stride;
+  if (ep) {
+    t.noise = ep->noise; t.noise_weight = ep->noise_weight; t.bias = ep->bias; t.channels = ep->channels;
+    t.noise_batch = ep->noise_batch; t.alpha = ep->alpha; t.act_scale = ep->act_scale;
+  }
   const int in_sz = p.in_h * p.in_w;
   int pb = 8192 / in_sz;                      // ~32 KB of LDS per block
   if (pb < 1) pb = 1;
@@ -753,8 +782,10 @@ int launch_planetile(const void* in, const void* kern, void* out, const UfdParam
   while (pb > 1 && (p.major + pb - 1) / pb < 2 * FMGAN_NUM_CU) pb >>= 1;
   t.pb = pb;
   const unsigned blocks = (unsigned)((p.major + pb - 1) / pb);
-  hipLaunchKernelGGL(ufd_planetile_f32, dim3(blocks), dim3(256), sizeof(float) * (size_t)pb * in_sz, s,
-                     (const float*)in, (const float*)kern, (float*)out, t);
+  if (ep) hipLaunchKernelGGL(ufd_planetile_f32<true>, dim3(blocks), dim3(256), sizeof(float) * (size_t)pb * in_sz, s,
+                             (const float*)in, (const float*)kern, (float*)out, t);
+  else hipLaunchKernelGGL(ufd_planetile_f32<false>, dim3(blocks), dim3(256), sizeof(float) * (size_t)pb * in_sz, s,
+                          (const float*)in, (const float*)kern, (float*)out, t);
   return fmgan_check_launch();
 }
 
@@ -882,9 +913,14 @@ extern "C" int fmgan_blur_noise_bias_act_path_f32(const float* input, const floa
   if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
   if (major == 0) return FMGAN_OK;
   if (!input || !kernel || !out) return FMGAN_EINVAL;
-  if (!rowmarch_ok(FMGAN_F32, p)) return FMGAN_EUNSUPPORTED;   // small planes: the caller keeps the two-pass form
   if ((long long)in_h * in_row_stride > 0x7fffffffLL) return FMGAN_EOVERFLOW;
   UfdEpilogue ep{noise, noise_weight, bias, channels, noise_batch, alpha, act_scale};
+  if (!rowmarch_ok(FMGAN_F32, p)) {
+    // small planes (the 4^2..32^2 upsampling layers): the plane-tile kernel reads the aligned-row layout and applies
+    // the epilogue in its store
+    if (force_path > 1 || !planetile_ok(FMGAN_F32, p)) return FMGAN_EUNSUPPORTED;
+    return launch_planetile(input, kernel, out, p, (hipStream_t)stream, &ep);
+  }
   return launch_rowmarch(input, kernel, out, p, (hipStream_t)stream, &ep, force_path);
 }
 

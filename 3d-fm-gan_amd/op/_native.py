@@ -188,12 +188,13 @@ def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_strid
 def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_stride, row_stride, kernel, pad, noise,
                         noise_weight, bias, alpha, scale, force_path=-1):
     """blur -> (+noise) -> +bias -> lrelu*scale in one pass over a strided f32 input; returns [B,C,out_h,out_w] or None
-    when the shape is not served by the row-march kernel (the caller then uses the two-pass form)."""
+    when neither the row-march kernels (out_w >= 64) nor the plane-tile kernel (planes up to ~110^2) serve the shape
+    (the caller then uses the two-pass form)."""
     k = kernel.contiguous()
     kh, kw = k.shape
     pad0, pad1 = pad
     out_h, out_w = upfirdn2d_out_size(in_h, in_w, kh, kw, 1, 1, 1, 1, pad0, pad1, pad0, pad1)
-    if out_w < 64 or out_h < 4:
+    if out_w <= 0 or out_h <= 0:
         return None
     out = torch.empty((batch, channels, out_h, out_w), dtype=torch.float32, device=device)
     nz = noise.contiguous() if noise is not None else None

@@ -320,8 +320,9 @@ class StyledConv(nn.Module):
             _native.modconv2d(input, conv.mfma_weight(), s, demod, 1, strided_out=(p0, ps, rs))
             out = _native.blur_noise_bias_act(p0, input.device, b, c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
                                               (pad0, pad1), noise, self.noise.weight, act.bias, act.negative_slope,
-                                              act.scale)          # blur + noise + bias + act in the blur's store
-            if out is None:   # small planes: blur from LDS, then the one-pass epilogue
+                                              act.scale)          # blur + noise + bias + act in the blur's store:
+            # row-march / LDS-DMA ring for planes >= 64 wide, plane-tile (whole planes in LDS) for the 8^2..32^2 layers
+            if out is None:   # shapes neither kernel serves (planes > ~110^2 narrower than 64): two passes
                 out = _native.upfirdn2d_strided(p0, input.device, b * c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
                                                 pad0, pad1, pad0, pad1).view(b, c, oh, ow)
                 out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)

@@ -107,8 +107,9 @@ int fmgan_upfirdn2d_strided(int dtype, const void *input, const void *kernel, vo
  *   out[b,c,y,x] = lrelu( (blur(in)[b,c,y,x] + noise_weight[0]*noise[b or 0,y,x]) + bias[c] ) * act_scale
  * in [batch*channels planes, in_h, in_w] with element strides as in fmgan_upfirdn2d_strided; out contiguous
  * [batch,channels,out_h,out_w]; noise [noise_batch (1|batch), out_h*out_w] or NULL; bias [channels] or NULL.
- * Served by the row-march kernel only (out_w >= 64): FMGAN_EUNSUPPORTED otherwise — the caller then runs
- * fmgan_upfirdn2d(_strided) followed by fmgan_noise_bias_act_f32, which gives bit-identical results.
+ * Served by the row-march kernels (out_w >= 64) and, for small planes (in_h*in_w <= 12288: the 4^2..32^2 upsampling
+ * layers), by the plane-tile kernel; FMGAN_EUNSUPPORTED otherwise — the caller then runs fmgan_upfirdn2d(_strided)
+ * followed by fmgan_noise_bias_act_f32, which gives bit-identical results (same kernel family, same roundings).
  */
 int fmgan_blur_noise_bias_act_f32(const float *input, const float *kernel, float *out,
                                   int batch, int channels, int in_h, int in_w,

@@ -133,8 +133,38 @@ def test_blur_with_fused_epilogue_matches_two_passes(cfg):
     # without noise / bias
     y0 = _native.blur_noise_bias_act(p0, dev(), b, c, 2 * hw + 1, 2 * hw + 1, ps, rs, k, (1, 1), None, None, None, 0.2, 2 ** 0.5)
     assert torch.equal(y0, _native.noise_bias_act(y2, None, None, None, 0.2, 2 ** 0.5))
-    # small planes are not served: the caller falls back
-    assert _native.blur_noise_bias_act(p0, dev(), b, c, 17, 17, ps, rs, k, (1, 1), None, None, None, 0.2, 1.0) is None
+
+
+@pytest.mark.parametrize('cfg', [(8, 512, 4, 8), (3, 40, 8, 1), (2, 24, 16, 2), (1, 7, 31, 1), (2, 3, 50, 2)])
+def test_small_plane_blur_with_fused_epilogue(cfg):
+    """The 4^2 -> 8^2 ... 16^2 -> 32^2 upsampling layers (and any plane narrower than 64): the plane-tile kernel reads the
+    aligned-row intermediate and applies noise + bias + lrelu in its store.  Bitwise equal to blur + fmgan_noise_bias_act,
+    the blur itself against the C oracle, NaN padding must not leak."""
+    from op import _native
+    from oracle import c_oracle
+    b, c, hw, nb = cfg
+    n = 2 * hw + 1
+    k = cases.make_fir('blur4').to(dev())
+    x = synth.tensor(f'spf/{cfg}/x', (b * c, n, n)).to(dev())
+    nz = synth.tensor(f'spf/{cfg}/n', (nb, 1, 2 * hw, 2 * hw)).to(dev())
+    nw = torch.tensor([-0.83], device=dev())
+    bias = synth.tensor(f'spf/{cfg}/b', (c,)).to(dev())
+    buf, p0, ps, rs = _native.aligned_rows_buffer(b, c, n, n, 1, dev())
+    buf.fill_(float('nan'))
+    buf[:, :, 1:n + 1] = x
+    assert _native.lib().fmgan_upfirdn2d_select(0, b * c, n, n, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1) == (2 if 2 * hw < 64 else 1)
+    y2 = _native.upfirdn2d_strided(p0, dev(), b * c, n, n, ps, rs, k, 1, 1, 1, 1).view(b, c, 2 * hw, 2 * hw)
+    yc = _native.upfirdn2d(x.reshape(b * c, n, n, 1), k, 1, 1, 1, 1, 1, 1, 1, 1).view(b, c, 2 * hw, 2 * hw)
+    assert torch.equal(y2, yc)                                  # strided read == contiguous read
+    ref = c_oracle.upfirdn2d(x[:3].reshape(3, n, n, 1).cpu().numpy(), k.cpu().numpy(), (1, 1), (1, 1), (1, 1, 1, 1))
+    np.testing.assert_allclose(y2.reshape(b * c, 2 * hw, 2 * hw)[:3].cpu().numpy().reshape(ref.shape), ref, **OP_TOL)
+    y = _native.blur_noise_bias_act(p0, dev(), b, c, n, n, ps, rs, k, (1, 1), nz, nw, bias, 0.2, 2 ** 0.5)
+    assert y is not None and not torch.isnan(y).any()
+    assert torch.equal(y, _native.noise_bias_act(y2, nz, nw, bias, 0.2, 2 ** 0.5))
+    y0 = _native.blur_noise_bias_act(p0, dev(), b, c, n, n, ps, rs, k, (1, 1), None, None, None, 0.2, 2 ** 0.5)
+    assert torch.equal(y0, _native.noise_bias_act(y2, None, None, None, 0.2, 2 ** 0.5))
+    # insisting on a row-march variant for such planes is refused, not silently served by another kernel
+    assert _native.blur_noise_bias_act(p0, dev(), b, c, n, n, ps, rs, k, (1, 1), nz, nw, bias, 0.2, 1.0, force_path=5) is None
 
 
 @pytest.mark.parametrize('cfg', [

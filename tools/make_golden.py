@@ -289,6 +289,27 @@ def gen_e2e_grad():
     print('e2e_grad', len(out))
 
 
+def gen_e2e_grad_latents():
+    """The encoder outputs of the e2e_grad case (reference modules, fp32 and fp64): with them a test can run the
+    Generator's forward + backward ALONE on exactly the inputs the reference's Generator saw, so that only this repo's
+    own bit-reproducible kernels stand between it and the `g/*` gradients of e2e_grad.npz (no MIOpen kernel involved)."""
+    c = cases.E2E_GRAD_CASE
+    out = {}
+    n_latent = int(np.log2(c['size'])) * 2 - 2
+    with torch.no_grad():
+        for dt, sfx in ((torch.float32, ''), (torch.float64, '64')):
+            e_tsr, e_w, e_wp = build_encoders(n_latent)
+            for m in (e_tsr, e_w, e_wp):
+                m.to(dt)
+            p = synth.tensor(c['name'] + '/photo', (c['b'], 3, 256, 256), dist='uniform').to(dt)
+            r = synth.tensor(c['name'] + '/render', (c['b'], 3, 256, 256), dist='uniform').to(dt)
+            out['e_tsr' + sfx] = npy(e_tsr(p if c['tsr_encode'] == 'Photo Image' else r))
+            out['e_w' + sfx] = npy(e_w(r))
+            out['e_wplus' + sfx] = npy(e_wp(p))
+    np.savez_compressed(os.path.join(OUT, 'e2e_grad_latents.npz'), **out)
+    print('e2e_grad_latents', {k: v.shape for k, v in out.items()})
+
+
 def gen_fp64():
     """The reference modules in float64 on the same inputs/weights: the yardstick for 'how far is an fp32 result from
     the exact value'.  tests compare |HIP - fp64| with |reference fp32 (the golden files above) - fp64|."""
@@ -478,9 +499,10 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     which = sys.argv[1:] or ['upfirdn2d', 'fused_act', 'modules', 'generator', 'e2e', 'discriminator', 'image_io',
-                             'e2e_grad', 'fp64', 'train_step', 'face_id', 'train_step_1024']
+                             'e2e_grad', 'e2e_grad_latents', 'fp64', 'train_step', 'face_id', 'train_step_1024']
     for w in which:
         {'upfirdn2d': gen_upfirdn2d, 'fused_act': gen_fused_act, 'modules': gen_modules,
          'generator': gen_generator, 'e2e': gen_encoders_e2e, 'discriminator': gen_discriminator,
          'image_io': gen_image_io, 'e2e_grad': gen_e2e_grad, 'fp64': gen_fp64, 'train_step': gen_train_step,
-         'train_step_1024': gen_train_step_1024, 'face_id': gen_face_id}[w]()
+         'train_step_1024': gen_train_step_1024, 'face_id': gen_face_id,
+         'e2e_grad_latents': gen_e2e_grad_latents}[w]()
