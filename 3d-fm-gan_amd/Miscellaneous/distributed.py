@@ -208,13 +208,14 @@ class Replica(nn.Module):
         return self.module(*args, **kwargs)
 
 
-def data_parallel(module, device=None, overlap=True, find_unused_parameters=None, single_rank_ddp=False):
+def data_parallel(module, device=None, overlap=True, find_unused_parameters=True, single_rank_ddp=False):
     """DataParallel replacement: DDP (bucketed RCCL all-reduce overlapped with backward) when a process group is up
-    and the module has trainable parameters, else a plain Replica.  find_unused_parameters: None = only for a
-    synthesis network, whose mapping network and constant input the 3-encoder scheme leaves unused
-    (input_is_latent=True, use_external_input_tensor=True; Util/network_util.py:329-330) — DDP would otherwise stall on
-    their buckets; the encoders and the discriminator use every parameter in every backward, and the graph walk that
-    flag costs per iteration is not paid for them (pass True for a pSp encoder whose heads are partly sliced away)."""
+    and the module has trainable parameters, else a plain Replica.  find_unused_parameters defaults to True, the safe
+    choice for an arbitrary module (DDP silently mis-reduces or stalls on parameters that receive no gradient): the
+    3-encoder scheme leaves the Generator's mapping network and constant input unused (input_is_latent=True,
+    use_external_input_tensor=True; Util/network_util.py:329-330).  Callers that know a network uses every parameter in
+    every backward — the encoders with all W+ columns co-modulated, the discriminator — pass False and save the graph
+    walk per iteration (train_3_encoder.Trainer, bench.py do)."""
     if device is not None:
         module = module.to(device)
     # modules that re-lay their conv weights for the GPU (pSp encoder: NHWC) do it now, so that DDP's bucket views are
@@ -222,8 +223,6 @@ def data_parallel(module, device=None, overlap=True, find_unused_parameters=None
     relayout = getattr(module, '_to_channels_last', None)
     if relayout is not None and getattr(module, 'channels_last', False) and next(module.parameters()).is_cuda:
         relayout()
-    if find_unused_parameters is None:
-        find_unused_parameters = hasattr(module, 'style') and hasattr(module, 'to_rgbs')      # stylegan2.Generator
     if (_active() and (get_world_size() > 1 or single_rank_ddp) and overlap and
             any(p.requires_grad for p in module.parameters())):
         ids = [device.index] if (device is not None and device.type == 'cuda') else None

@@ -11,13 +11,14 @@
 //   kind 1  wt[i][t][o] = scale * W[o][i][t]   and   wsq[o][i] = sum_t W[o][i][t]^2
 //           (MFMA A-operand layout of ModulatedConv2d + the demodulation sums; same arithmetic, same order as
 //           modconv_weight_prep_f32 / modconv_wsq_f32 in modconv.hip -> identical bits)
-// Kind 1 is an LDS-tiled transpose: a block owns 32 output channels x 8 input channels x ktaps; reads are runs of
-// 8*ktaps contiguous floats per output channel, writes are runs of 32 contiguous floats.
+// Kind 1 is an LDS-tiled transpose: a block owns 64 output channels x 16 input channels x ktaps; reads are runs of
+// 16*ktaps contiguous floats per output channel (576 B for 3x3), writes are runs of 64 contiguous floats (256 B).
+// (32 x 8 tiles — 288-byte reads, 128-byte writes — ran the refresh of Generator(1024) at ~0.8 TB/s.)
 #include "common.h"
 
 namespace {
 
-constexpr int LW_TO = 32, LW_TI = 8, LW_MAXT = 9;
+constexpr int LW_TO = 64, LW_TI = 16, LW_MAXT = 9;
 constexpr int LW_ELEMS0 = 2048;   // kind 0: elements per block
 
 __global__ __launch_bounds__(256) void live_weights_f32(const fmgan_refresh_entry* __restrict__ table, int n_entries) {
@@ -58,11 +59,13 @@ __global__ __launch_bounds__(256) void live_weights_f32(const fmgan_refresh_entr
   }
   float* __restrict__ wsq = (float*)e.dst2;
   if (wsq) {
-    const int o = threadIdx.x / LW_TI, i = threadIdx.x % LW_TI;     // 32 x 8 = 256 threads
-    if (o0 + o < e.cout && i < i_n) {
-      float q = 0.f;
-      for (int t = 0; t < kt; ++t) { const float w = tile[o][i * kt + t]; q = fmaf(w, w, q); }
-      wsq[(long long)(o0 + o) * e.cin + i0 + i] = q;
+    for (int idx = threadIdx.x; idx < LW_TO * LW_TI; idx += 256) {
+      const int o = idx / LW_TI, i = idx % LW_TI;
+      if (o0 + o < e.cout && i < i_n) {
+        float q = 0.f;
+        for (int t = 0; t < kt; ++t) { const float w = tile[o][i * kt + t]; q = fmaf(w, w, q); }
+        wsq[(long long)(o0 + o) * e.cin + i0 + i] = q;
+      }
     }
   }
 }

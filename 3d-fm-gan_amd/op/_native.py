@@ -18,6 +18,13 @@ _DTYPES = {torch.float32: F32, torch.float64: F64, torch.float16: F16}
 
 _lib = None
 
+# Under torch.autocast (BASELINE config 5's bf16 leg) the MIOpen convolutions hand bf16 tensors to their consumers; the
+# HIP kernels compute in fp32 (their reference counterparts dispatch float / double / half only): every custom autograd
+# Function of this package is entered with autocast off and its floating-point CUDA inputs cast to fp32.  A no-op when
+# autocast is not active.
+amp_fwd = torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+amp_bwd = torch.amp.custom_bwd(device_type='cuda')
+
 
 def _sig(fn, argtypes, restype=ctypes.c_int):
     fn.argtypes = argtypes
@@ -55,6 +62,10 @@ def lib():
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, i, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
+    _sig(L.fmgan_modconv_weight_bf16_bytes, [i] * 3, ll)
+    _sig(L.fmgan_modconv_weight_to_bf16, [vp, vp, i, i, i, vp])
+    _sig(L.fmgan_modconv2d_bf16_supported, [i] * 6)
+    _sig(L.fmgan_modconv2d_bf16, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp])
     _sig(L.fmgan_modconv2d_rgb_fusable, [i] * 5)
     _sig(L.fmgan_torgb_weight_mod_f32, [vp] * 3 + [i] * 3 + [f, vp])
     _sig(L.fmgan_modconv2d_rgb_f32, [vp] * 5 + [i] * 5 + [vp] * 3 + [i, i, f, f] + [vp] * 4 + [i, vp])
@@ -346,10 +357,46 @@ def aligned_rows_buffer(b, c, oh, ow, pad0, device):
     return buf, buf.data_ptr() + 4 * off, oh * rs, rs
 
 
+# Contraction precision of modconv2d: 'f32' (default, the parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulation;
+# BASELINE config 5's reduced-precision leg).  Set through the context manager only.
+_mc_precision = 'f32'
+
+
+class modconv_precision:
+    """`with modconv_precision('bf16'):` — every modconv2d call inside (forward and data-gradient contractions of the
+    modulated conv) whose shape the bf16 kernel serves runs on v_mfma_f32_32x32x16_bf16; the rest stay fp32."""
+
+    def __init__(self, precision):
+        if precision not in ('f32', 'bf16'):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.precision = precision
+
+    def __enter__(self):
+        global _mc_precision
+        self.prev, _mc_precision = _mc_precision, self.precision
+        return self
+
+    def __exit__(self, *exc):
+        global _mc_precision
+        _mc_precision = self.prev
+        return False
+
+
+def modconv_weight_to_bf16(wt):
+    """fp32 MFMA layout wt [cin, taps, cout] (modconv_weight_prep) -> bf16 operand image (opaque int16 tensor)."""
+    cin, taps, cout = wt.shape
+    nbytes = lib().fmgan_modconv_weight_bf16_bytes(cin, cout, taps)
+    wtb = torch.empty(nbytes // 2, dtype=torch.int16, device=wt.device)
+    with on_device(wt) as stream:
+        check(lib().fmgan_modconv_weight_to_bf16(ptr(wt), ptr(wtb), cin, cout, taps, stream), 'modconv_weight_to_bf16')
+    return wtb
+
+
 def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=None, fuse_act=False, alpha=0.2,
-              act_scale=2 ** 0.5, strided_out=None):
+              act_scale=2 ** 0.5, strided_out=None, precision=None):
     """x [B,cin,H,W] f32, wt from modconv_weight_prep (3x3), style [B,cin], demod [B,cout] or None.
-    strided_out = (ptr, plane_stride, row_stride) writes into a caller-owned strided buffer and returns None."""
+    strided_out = (ptr, plane_stride, row_stride) writes into a caller-owned strided buffer and returns None.
+    precision: None = the ambient modconv_precision (default 'f32')."""
     require_gpu(x, 'input')
     x = x.contiguous()
     style = style.contiguous()
@@ -363,6 +410,16 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
         out = None
         out_ptr, ops, ors = strided_out
     nz = noise.contiguous() if noise is not None else None
+    if (precision or _mc_precision) == 'bf16' and lib().fmgan_modconv2d_bf16_supported(b, cin, cout, h, w, mode):
+        wtb = modconv_weight_to_bf16(wt)
+        with on_device(x) as stream:
+            tok = _observer.begin('modconv2d_bf16', (b, cin, cout, h, w, mode))
+            check(lib().fmgan_modconv2d_bf16(ptr(x), ptr(wtb), ptr(style), ptr(demod), out_ptr, b, cin, cout, h, w, mode,
+                                             ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
+                                             int(bool(fuse_act)), float(alpha), float(act_scale), ops, ors, stream),
+                  'modconv2d_bf16')
+            _observer.end(tok)
+        return out
     ws_bytes = lib().fmgan_modconv2d_workspace_bytes(b, cin, cout, h, w, mode)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with on_device(x) as stream:

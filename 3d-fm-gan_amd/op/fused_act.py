@@ -14,6 +14,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import _native
+from ._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 
 
 class _Ext:
@@ -30,6 +31,7 @@ def _reduce_dims(t):
 
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, grad_output, out, bias, negative_slope, scale):
         ctx.save_for_backward(out)
         ctx.cfg = (negative_slope, scale)
@@ -45,6 +47,7 @@ class FusedLeakyReLUFunctionBackward(Function):
         return grad_input, grad_bias
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gradgrad_input, gradgrad_bias):
         out, = ctx.saved_tensors
         negative_slope, scale = ctx.cfg
@@ -54,6 +57,7 @@ class FusedLeakyReLUFunctionBackward(Function):
 
 class FusedLeakyReLUFunction(Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, input, bias, negative_slope, scale):
         ctx.has_bias = bias is not None
         out = fused.fused_bias_act(input, bias if ctx.has_bias else input.new_empty(0), input.new_empty(0), 3, 0,
@@ -63,6 +67,7 @@ class FusedLeakyReLUFunction(Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         out, = ctx.saved_tensors
         negative_slope, scale = ctx.cfg

@@ -18,6 +18,7 @@ from torch.autograd import Function
 from torch.nn import functional as F
 
 from . import _native
+from ._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 
 # Weight gradient of the plain conv: this repo's fmgan_modconv_wgrad_f32 (64 x 64 tile, sliding 3 x 3 window,
 # register-prefetch pipeline; bit-reproducible) measures 111-123 TFLOP/s on MI355X against 96-116 for MIOpen's fp32
@@ -95,12 +96,14 @@ class DenseConv(Function):
     """C_m(u, W): u [B,Cin,H,W] f32, W [Cout,Cin,3,3]."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, u, w4, mode):
         ctx.save_for_backward(u, w4)
         ctx.mode = mode
         return _kernel_conv(u.contiguous(), w4, mode, 0)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         u, w4 = ctx.saved_tensors
         gu = DenseConvDgrad.apply(g, w4, ctx.mode, tuple(u.shape[2:])) if ctx.needs_input_grad[0] else None
@@ -112,6 +115,7 @@ class DenseConvDgrad(Function):
     """D_m(g, W): the adjoint of C_m(., W), again on the MFMA kernel (roles of Cin / Cout swapped)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, g, w4, mode, in_hw):
         ctx.save_for_backward(g, w4)
         ctx.mode = mode
@@ -123,6 +127,7 @@ class DenseConvDgrad(Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, h):
         g, w4 = ctx.saved_tensors
         gg = DenseConv.apply(h, w4, ctx.mode) if ctx.needs_input_grad[0] else None
@@ -134,12 +139,14 @@ class DenseConvWgrad(Function):
     """G_m(u, g): weight gradient of C_m."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, u, g, mode):
         ctx.save_for_backward(u, g)
         ctx.mode = mode
         return _wgrad(u.contiguous(), g.contiguous(), mode).contiguous()
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, hw):
         u, g = ctx.saved_tensors
         hw = hw.contiguous()
@@ -184,6 +191,7 @@ class ModulatedConv2dFunction(Function):
     """
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, s, wt, demodulate, mode, scale):
         demod = _native.modconv_demod(weight, s, scale) if demodulate else None
         out = _native.modconv2d(x, wt, s, demod, mode)
@@ -193,6 +201,7 @@ class ModulatedConv2dFunction(Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         demodulate, mode, scale = ctx.cfg
         x, weight, s = ctx.saved_tensors[:3]
@@ -257,6 +266,7 @@ class ToRGBFunction(Function):
     """1x1 modulated conv without demodulation + bias + skip add in one HBM pass."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, s, bias, skip, scale):
         out = _native.torgb(x, weight, s, bias, skip, scale)
         ctx.has_skip = skip is not None
@@ -265,6 +275,7 @@ class ToRGBFunction(Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         x, weight, s, bias = ctx.saved_tensors[:4]
         scale = ctx.scale

@@ -15,6 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import _native
+from ._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 
 
 class _Ext:
@@ -36,6 +37,7 @@ class UpFirDn2dBackward(Function):
     """grad_input = upfirdn2d(grad_output; flip(k), up<->down, g_pad); its own backward is the forward op."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
         go = grad_output.reshape(-1, out_size[0], out_size[1], 1)
         gi = upfirdn2d_op.upfirdn2d(go, grad_kernel, down[0], down[1], up[0], up[1], *g_pad)
@@ -44,6 +46,7 @@ class UpFirDn2dBackward(Function):
         return gi.view(in_size)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gradgrad_input):
         kernel, = ctx.saved_tensors
         up, down, pad, in_size, out_size = ctx.cfg
@@ -54,6 +57,7 @@ class UpFirDn2dBackward(Function):
 
 class UpFirDn2d(Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, input, kernel, up, down, pad):
         batch, channel, in_h, in_w = input.shape
         kh, kw = kernel.shape
@@ -66,6 +70,7 @@ class UpFirDn2d(Function):
         return out.view(-1, channel, out_h, out_w)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         kernel, grad_kernel = ctx.saved_tensors
         up, down, pad, g_pad, in_size, out_size = ctx.cfg

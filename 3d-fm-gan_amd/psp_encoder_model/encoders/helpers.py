@@ -4,6 +4,8 @@ from collections import namedtuple
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from op._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 from torch.nn import (AdaptiveAvgPool2d, BatchNorm2d, Conv2d, MaxPool2d, Module, ReLU, Sequential, Sigmoid)
 
 
@@ -15,11 +17,13 @@ class _PReLUFunction(torch.autograd.Function):
     formulas run as differentiable torch ops."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
         return F.prelu(x, weight)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad):
         x, weight = ctx.saved_tensors
         if not torch.is_grad_enabled():

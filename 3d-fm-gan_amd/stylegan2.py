@@ -19,6 +19,7 @@ from torch.nn import functional as F
 
 from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from op import _native, modconv
+from op._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 from op.live_weights import LiveWeights, live
 from Util.streams import side_streams, run_on, overlap_ok
 
@@ -236,11 +237,13 @@ class _NoiseInjectionFunction(autograd.Function):
     with the noise in float64.  The backward is made of differentiable ops, so it also serves create_graph=True."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, image, weight, noise):
         ctx.save_for_backward(weight, noise)
         return image + weight * noise
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, go):
         weight, noise = ctx.saved_tensors
         g_weight = g_noise = None

@@ -141,7 +141,8 @@ def make_train_step(nets, batch, device, rank, world):
     from Util.network_util import Forward_Inference_3_Encoder
     for m in nets.values():
         m.requires_grad_(True)
-    wrapped = {k: D.data_parallel(m, device) for k, m in nets.items()}
+    # only the Generator has parameters without a gradient (mapping network, constant input)
+    wrapped = {k: D.data_parallel(m, device, find_unused_parameters=(k == 'g')) for k, m in nets.items()}
     gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
     photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)
     render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(device)

@@ -270,6 +270,29 @@ int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
                         void *workspace, long long workspace_bytes, void *stream);
 
 /*
+ * Reduced-precision form of fmgan_modconv2d_f32 for BASELINE config 5's bf16 leg (NOT the parity path; the reference has
+ * no such path: its ModulatedConv2d is F.conv2d in the tensors' dtype, stylegan2.py:250-298, and its op kernels
+ * dispatch float / double / half only, op/upfirdn2d_kernel.cu:311): the same operator with both MFMA operands rounded to
+ * bf16 (RNE) — the scaled weight, and the modulated activation style[b,i]*in[b,i,..] on its way into LDS — and fp32
+ * accumulation on v_mfma_f32_32x32x16_bf16; fp32 tensors in HBM on both sides, same arguments and epilogue.
+ *   fmgan_modconv_weight_bf16_bytes / fmgan_modconv_weight_to_bf16: convert the fp32 MFMA layout wt[cin][taps][cout]
+ *       (fmgan_modconv_weight_prep_f32, any kind; cin / cout = the CONV's input / output channels) into the bf16 operand
+ *       image [cin/16][tap][2][cout padded to 32][8].
+ *   fmgan_modconv2d_bf16_supported: 1 when the shape is served (cin % 16 == 0, cout % 32 == 0, position grid >= 32 wide
+ *       and >= 4 high, 32-bit buffer ranges); otherwise fmgan_modconv2d_bf16 returns FMGAN_EUNSUPPORTED and the caller
+ *       keeps the fp32 kernel.  mode 1 writes output rows < 2h / columns < 2w from the MFMA launch and the last row and
+ *       column from a direct kernel on the same rounded operands.
+ */
+long long fmgan_modconv_weight_bf16_bytes(int cin, int cout, int ktaps);
+int fmgan_modconv_weight_to_bf16(const float *wt, void *wt_bf16, int cin, int cout, int ktaps, void *stream);
+int fmgan_modconv2d_bf16_supported(int batch, int cin, int cout, int h, int w, int mode);
+int fmgan_modconv2d_bf16(const float *in, const void *wt_bf16, const float *style, const float *demod, float *out,
+                         int batch, int cin, int cout, int h, int w, int mode,
+                         const float *noise, const float *noise_weight, const float *bias,
+                         int noise_batch, int fuse_act, float alpha, float act_scale,
+                         long long out_plane_stride, int out_row_stride, void *stream);
+
+/*
  * Plain (mode 0) modulated conv with the FOLLOWING ToRGB layer folded into its epilogue.  In the reference these are
  * two modules and three HBM passes over the activation (StyledConv conv2 -> ToRGB, stylegan2.py:646-651 calling
  * :360-376 and :393-404).  When one block holds every output channel of its pixels (cout <= the tile's channel

@@ -88,6 +88,26 @@ def modulated_conv2d(x, w_latent, weight, mod_weight, mod_bias, demodulate=True,
     return out.view(batch, out_channel, out.shape[2], out.shape[3])
 
 
+def modconv_bf16_reference(x, weight, style, demod, mode, scale):
+    """What fmgan_modconv2d_bf16 computes, in float64: the input-modulated restatement of ModulatedConv2d
+    (stylegan2.py:250-298; mode 0 plain / 1 transposed stride 2 / 2 stride-2 valid) with BOTH contraction operands
+    rounded to bfloat16 (round-to-nearest-even) — the scaled weight fl32(scale*W) and the modulated activation
+    fl32(x*style) — exact products and a wide accumulator.  x [B,Cin,H,W], weight [Cout,Cin,3,3], style [B,Cin],
+    demod [B,Cout] or None.  The reduced-precision leg has no counterpart in the reference (parity unpinned by
+    construction): this is the definition the kernel is tested against."""
+    u = (x.float() * style.float()[:, :, None, None]).to(torch.bfloat16).double()
+    wq = (weight.float() * torch.tensor(scale, dtype=torch.float32)).to(torch.bfloat16).double()
+    if mode == 0:
+        y = F.conv2d(u, wq, padding=1)
+    elif mode == 1:
+        y = F.conv_transpose2d(u, wq.transpose(0, 1), stride=2)
+    else:
+        y = F.conv2d(u, wq, stride=2)
+    if demod is not None:
+        y = y * demod.double()[:, :, None, None]
+    return y
+
+
 def styled_conv(sd, prefix, x, w_latent, noise, upsample, blur_kernel=(1, 3, 3, 1)):
     """StyledConv.forward, stylegan2.py:360-376 (conv -> NoiseInjection :307-312 -> FusedLeakyReLU)."""
     out = modulated_conv2d(x, w_latent, sd[prefix + '.conv.weight'], sd[prefix + '.conv.modulation.weight'],

@@ -1,0 +1,127 @@
+"""GPU tests of the reduced-precision modulated conv (fmgan_modconv2d_bf16, BASELINE config 5's bf16 leg).
+
+Not a parity row: the reference has no bf16 path.  The kernel is held to its own definition — bf16-rounded operands,
+exact products, fp32 accumulation — through oracle/torch_oracle.py::modconv_bf16_reference (float64 convolution of the
+rounded operands): 2e-5 of max|out|, i.e. fp32 summation error only; and to the bf16-sized distance from the fp32 kernel
+SURVEY §8c states for this configuration (5e-2 on [-1,1] images end to end; per layer a few 1e-3 of max|out|)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+CASES = [
+    # (b, cin, cout, h, w, mode): every tile configuration (cout 32 / >= 64), ragged grids, several chunks
+    (2, 32, 32, 64, 64, 0), (1, 16, 32, 40, 33, 0), (2, 64, 64, 32, 32, 0), (1, 48, 96, 37, 70, 0), (3, 128, 160, 36, 32, 0),
+    (2, 32, 32, 64, 64, 1), (1, 16, 32, 9, 33, 1), (2, 64, 64, 32, 32, 1), (1, 48, 96, 21, 45, 1),
+    (2, 32, 32, 129, 129, 2), (1, 16, 64, 75, 67, 2), (1, 64, 32, 67, 131, 2), (2, 32, 96, 11, 65, 2),
+]
+
+
+def _inputs(cfg):
+    b, cin, cout, h, w, mode = cfg
+    x = synth.tensor(f'bf/{cfg}/x', (b, cin, h, w))
+    wgt = synth.tensor(f'bf/{cfg}/w', (cout, cin, 3, 3))
+    s = synth.tensor(f'bf/{cfg}/s', (b, cin), shift=1.0, scale=0.5)
+    return x, wgt, s, float(np.float32(1.0 / np.sqrt(cin * 9)))
+
+
+@pytest.mark.parametrize('cfg', CASES)
+@pytest.mark.parametrize('demod', [True, False])
+def test_bf16_kernel_matches_its_definition(cfg, demod):
+    from op import _native
+    from oracle import torch_oracle as T
+    b, cin, cout, h, w, mode = cfg
+    x, wgt, s, scale = _inputs(cfg)
+    assert _native.lib().fmgan_modconv2d_bf16_supported(b, cin, cout, h, w, mode) == 1
+    xd, wd, sd = x.to(dev()), wgt.to(dev()), s.to(dev())
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale) if demod else None
+    y = _native.modconv2d(xd, wt, sd, dm, mode, precision='bf16')
+    ref = T.modconv_bf16_reference(x, wgt, s, None if dm is None else dm.cpu(), mode, scale).numpy()
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=2e-5 * float(np.abs(ref).max()), rtol=0)
+    # bf16-sized distance from the fp32 kernel (operand rounding 2^-9 each, averaged over cin*9 products)
+    y32 = _native.modconv2d(xd, wt, sd, dm, mode, precision='f32')
+    err = float((y - y32).abs().max() / y32.abs().max())
+    assert 1e-5 < err < 1e-2, err
+    with _native.modconv_precision('bf16'):
+        assert torch.equal(_native.modconv2d(xd, wt, sd, dm, mode), y)      # ambient switch, bit-reproducible
+    assert torch.equal(_native.modconv2d(xd, wt, sd, dm, mode), y32)        # and it is off again outside
+
+
+def test_bf16_fused_epilogue_and_strided_output():
+    """Plain conv with noise + bias + lrelu in the epilogue, and the transposed conv writing the aligned-row intermediate:
+    same values as the separate steps on the bf16 result."""
+    from op import _native
+    cfg = (2, 32, 64, 40, 64, 0)
+    b, cin, cout, h, w, _ = cfg
+    x, wgt, s, scale = _inputs(cfg)
+    d = dev()
+    xd, wd, sd = x.to(d), wgt.to(d), s.to(d)
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale)
+    nz = synth.tensor('bf/ep/n', (b, 1, h, w)).to(d)
+    nw = torch.tensor([0.41], device=d)
+    bias = synth.tensor('bf/ep/b', (cout,)).to(d)
+    plain = _native.modconv2d(xd, wt, sd, dm, 0, precision='bf16')
+    fused = _native.modconv2d(xd, wt, sd, dm, 0, noise=nz, noise_weight=nw, bias=bias, fuse_act=True, precision='bf16')
+    assert torch.equal(fused, _native.noise_bias_act(plain, nz, nw, bias, 0.2, 2 ** 0.5))
+    up = _native.modconv2d(xd, wt, sd, dm, 1, precision='bf16')
+    oh, ow = 2 * h + 1, 2 * w + 1
+    buf, p0, ps, rs = _native.aligned_rows_buffer(b, cout, oh, ow, 1, d)
+    buf.fill_(float('nan'))
+    _native.modconv2d(xd, wt, sd, dm, 1, strided_out=(p0, ps, rs), precision='bf16')
+    assert torch.equal(buf[:, :, 1:1 + ow].reshape(b, cout, oh, ow), up)
+    assert torch.isnan(buf[:, :, 0]).all() and torch.isnan(buf[:, :, 1 + ow:]).all()
+
+
+def test_bf16_unsupported_shapes_keep_the_fp32_kernel():
+    from op import _native
+    L = _native.lib()
+    for cfg in ((2, 12, 32, 64, 64, 0), (2, 32, 48, 64, 64, 0), (2, 32, 32, 16, 16, 0), (2, 512, 512, 4, 4, 1), (1, 32, 32, 40, 40, 2)):
+        assert L.fmgan_modconv2d_bf16_supported(*cfg) == 0, cfg
+    cfg = (2, 12, 32, 64, 64, 0)
+    x, wgt, s, scale = _inputs(cfg)
+    xd, wd, sd = x.to(dev()), wgt.to(dev()), s.to(dev())
+    wt = _native.modconv_weight_prep(wd, scale)
+    with _native.modconv_precision('bf16'):
+        y = _native.modconv2d(xd, wt, sd, None, 0)
+    assert torch.equal(y, _native.modconv2d(xd, wt, sd, None, 0))
+
+
+def test_bf16_generator_forward_within_stated_tolerance():
+    """Generator(256) forward with every served layer on the bf16 contraction vs the fp32 path: SURVEY §8c's stated
+    tolerance for the bf16 configuration is 5e-2 on [-1,1]-scaled images; the synthetic weights here give images of
+    max ~8, so the bound is taken relative to max|image|."""
+    import stylegan2
+    from op import _native
+    G = stylegan2.Generator(256, 512, 2)
+    G.load_state_dict(synth.state_dict('generator', G.state_dict(), seed=4))
+    G = G.to(dev()).eval()
+    lat = synth.tensor('bf/g/lat', (2, G.n_latent, 512)).to(dev())
+    tsr = synth.tensor('bf/g/tsr', (2, 512, 4, 4)).to(dev())
+    kw = dict(latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True, external_input_tensor=tsr,
+              randomize_noise=False)
+    with torch.no_grad():
+        ref = G(None, **kw)
+        with _native.modconv_precision('bf16'):
+            img = G(None, **kw)
+    err = float((img - ref).abs().max() / ref.abs().max())
+    assert 1e-5 < err < 5e-2, err
+    # training graph (forward + data gradients on the bf16 kernel, weight gradients fp32): finite, close to fp32
+    G.requires_grad_(True)
+    tsr_g = tsr.clone().requires_grad_(True)
+    kw['external_input_tensor'] = tsr_g
+    g32, = torch.autograd.grad(G(None, **kw).abs().mean(), tsr_g)
+    with _native.modconv_precision('bf16'):
+        g16, = torch.autograd.grad(G(None, **kw).abs().mean(), tsr_g)
+    assert torch.isfinite(g16).all()
+    assert float((g16 - g32).abs().max() / g32.abs().max()) < 0.1

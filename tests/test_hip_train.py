@@ -233,14 +233,33 @@ def test_generator_only_backward_own_kernels_tight(golden):
     assert n == len([k for k in g.files if k.startswith('g/') and k.endswith('/n64')]) == 93
 
 
-def test_generator_only_backward_is_bit_reproducible():
-    G1, img1, _, _ = run_generator_only()
+@pytest.mark.parametrize('own_wgrad', [False, True])
+def test_generator_only_backward_is_bit_reproducible(own_wgrad, monkeypatch):
+    """Two runs in one process.  Default configuration: every gradient this repo's kernels produce is bit-identical; the
+    weight gradients of the six upsampling convs come from MIOpen's stride-2 fp32 wgrad (op/modconv.py HIP_WGRAD = 1:
+    its kernels are faster there and not run-to-run reproducible) and agree to rounding.  With HIP_WGRAD = 2 (own
+    stride-2 wgrad kernel) all 93 tensors are bit-identical and still meet the tight gate."""
+    from op import modconv
+    if own_wgrad:
+        monkeypatch.setattr(modconv, 'HIP_WGRAD', 2)
+    G1, img1, _, conds = run_generator_only()
     g1 = {n: p.grad.clone() for n, p in G1.named_parameters() if p.grad is not None}
+    if own_wgrad:
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_grad.npz'))
+        for name, p in G1.named_parameters():
+            if f'g/{name}/s' in g.files:
+                fl = max(OWN_FLOOR, 2e-6 * conds[name]) if name in conds else OWN_FLOOR
+                check_grads(g, 'g', [(name, p)], floor=fl, floor_norm=max(OWN_FLOOR_NORM, fl if name in conds else 0.0))
     del G1
     G2, img2, _, _ = run_generator_only()
     assert torch.equal(img1, img2)
+    miopen = {f'convs.{i}.conv.weight' for i in range(0, 12, 2)}       # transposed convs of Generator(256)
     for n, p in G2.named_parameters():
-        if p.grad is not None:
+        if p.grad is None:
+            continue
+        if n in miopen and not own_wgrad:
+            torch.testing.assert_close(p.grad, g1[n], atol=2e-5 * float(g1[n].abs().max()), rtol=0)
+        else:
             assert torch.equal(p.grad, g1[n]), n
 
 

@@ -14,7 +14,9 @@ def test_refresh_entry_layout_matches_library():
     assert _native.lib().fmgan_refresh_entry_bytes() == live_weights._ENTRY.itemsize
     L = _native.lib()
     assert L.fmgan_weight_refresh_blocks(0, 0, 0, 0, 5000) == 3
-    assert L.fmgan_weight_refresh_blocks(1, 70, 9, 9, 0) == 3 * 2
+    # kind 1: one block per 64 output channels x 16 input channels (csrc/live_weights.hip LW_TO x LW_TI)
+    assert L.fmgan_weight_refresh_blocks(1, 70, 9, 9, 0) == 2 * 1
+    assert L.fmgan_weight_refresh_blocks(1, 130, 40, 9, 0) == 3 * 3
     assert L.fmgan_weight_refresh_blocks(1, 8, 8, 25, 0) == -1
     assert L.fmgan_weight_refresh_f32(None, 0, 0, None) == 0
     assert L.fmgan_weight_refresh_f32(None, 3, 10, None) == -1
