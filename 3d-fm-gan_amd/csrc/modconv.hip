@@ -1968,3 +1968,102 @@ extern "C" int fmgan_torgb_f32(const float* in, const float* weight, const float
   else hipLaunchKernelGGL(torgb_f32<1>, dim3(gx, batch), dim3(256), lds, s, in, weight, style, bias, skip, out, cin, cout, hw, scale);
   return fmgan_check_launch();
 }
+
+// ------------------------------------------------------------------ ToRGB backward (HBM-bound, one pass over x)
+// out[b,c,p] = sum_i (scale * W[c,i] * s[b,i]) * x[b,i,p]  (stylegan2.py:389-404 without demodulation).  Its backward
+// needs  gx[b,i,p] = sum_c (scale * W[c,i] * s[b,i]) * go[b,c,p]  and  M[b,c,i] = sum_p go[b,c,p] * x[b,i,p]  (from which
+// gW[c,i] = scale * sum_b s[b,i] M[b,c,i] and gs[b,i] = scale * sum_c W[c,i] M[b,c,i] are [B,3,Cin] algebra).  The autograd
+// composite reads x twice and go many times through a grouped 1x1 convolution and its non-reproducible weight
+// gradient; here a block owns 16 input channels and a pixel range of one sample, reads its x planes ONCE, writes gx, and
+// keeps the 3 x 16 partial sums of M in registers over the whole range — one block-wide reduction at the end, one
+// partial row per (pixel split) that the caller sums in a fixed order (bit-reproducible).
+constexpr int TB_CT = 16;
+__global__ __launch_bounds__(256) void torgb_bwd_f32(const float* __restrict__ x, const float* __restrict__ go,
+                                                     const float* __restrict__ weight, const float* __restrict__ style,
+                                                     float* __restrict__ gx, float* __restrict__ mpart, int batch, int cin,
+                                                     int cout, int hw4, int chunk, float scale) {
+  __shared__ float wm[4][TB_CT];
+  __shared__ float red[4][4 * TB_CT];
+  const int b = blockIdx.z, i0 = blockIdx.y * TB_CT, split = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < 4 * TB_CT) {
+    const int c = tid / TB_CT, j = tid % TB_CT;
+    wm[c][j] = (c < cout && i0 + j < cin) ? scale * weight[c * cin + i0 + j] * style[(long long)b * cin + i0 + j] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][TB_CT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < TB_CT; ++j) acc[c][j] = 0.f;
+  const f32x4* go4 = reinterpret_cast<const f32x4*>(go) + (long long)b * cout * hw4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + ((long long)b * cin + i0) * hw4;
+  f32x4* gx4 = reinterpret_cast<f32x4*>(gx) + ((long long)b * cin + i0) * hw4;
+  const int p_end = min(hw4, (split + 1) * chunk);
+  const int nj = min(TB_CT, cin - i0);
+  for (int p = split * chunk + tid; p < p_end; p += 256) {
+    f32x4 g[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      g[c] = c < cout ? go4[(long long)c * hw4 + p] : z;
+    }
+#pragma unroll
+    for (int j = 0; j < TB_CT; ++j) {
+      if (j >= nj) break;
+      const f32x4 xv = x4[(long long)j * hw4 + p];
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float w = wm[c][j];
+        r.x = fmaf(w, g[c].x, r.x); r.y = fmaf(w, g[c].y, r.y); r.z = fmaf(w, g[c].z, r.z); r.w = fmaf(w, g[c].w, r.w);
+        acc[c][j] = fmaf(g[c].x, xv.x, fmaf(g[c].y, xv.y, fmaf(g[c].z, xv.z, fmaf(g[c].w, xv.w, acc[c][j]))));
+      }
+      gx4[(long long)j * hw4 + p] = r;
+    }
+  }
+  // block reduction of the 4 x 16 partials: wave butterfly, then the four waves in order
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < TB_CT; ++j) {
+      float v = acc[c][j];
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+      if ((tid & 63) == 0) red[tid >> 6][c * TB_CT + j] = v;
+    }
+  __syncthreads();
+  if (tid < 4 * TB_CT) {
+    const int c = tid / TB_CT, j = tid % TB_CT;
+    if (c < cout && i0 + j < cin)
+      mpart[(((long long)split * batch + b) * cout + c) * cin + i0 + j] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
+// pixel splits of the backward launch (= rows of the partial array [splits, batch, cout, cin]); 0: shape not served
+extern "C" int fmgan_torgb_backward_splits(int batch, int cin, int hw) {
+  if (batch <= 0 || cin <= 0 || hw <= 0 || (hw & 3)) return 0;
+  const int hw4 = hw >> 2;
+  const long long others = (long long)batch * ((cin + TB_CT - 1) / TB_CT);
+  long long s = (8LL * FMGAN_NUM_CU + others - 1) / others;      // ~8 blocks per CU in the grid
+  const long long smax = (hw4 + 511) / 512;                       // at least two float4 per lane and split
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  if (s > 1024) s = 1024;
+  return (int)s;
+}
+
+extern "C" int fmgan_torgb_backward_f32(const float* x, const float* grad_out, const float* weight, const float* style,
+                                        float* grad_x, float* m_partial, int batch, int cin, int cout, int hw, float scale,
+                                        void* stream) {
+  if (batch < 0 || cin <= 0 || cout <= 0 || cout > 4 || hw <= 0) return FMGAN_EINVAL;
+  if (batch == 0) return FMGAN_OK;
+  if (!x || !grad_out || !weight || !style || !grad_x || !m_partial) return FMGAN_EINVAL;
+  const int splits = fmgan_torgb_backward_splits(batch, cin, hw);
+  if (splits == 0 || ((((uintptr_t)x) | ((uintptr_t)grad_out) | ((uintptr_t)grad_x)) & 15) != 0) return FMGAN_EUNSUPPORTED;
+  if (batch > 65535) return FMGAN_EOVERFLOW;
+  const int hw4 = hw >> 2, chunk = (hw4 + splits - 1) / splits;
+  hipLaunchKernelGGL(torgb_bwd_f32, dim3(splits, (cin + TB_CT - 1) / TB_CT, batch), dim3(256), 0, (hipStream_t)stream, x,
+                     grad_out, weight, style, grad_x, m_partial, batch, cin, cout, hw4, chunk, scale);
+  return fmgan_check_launch();
+}

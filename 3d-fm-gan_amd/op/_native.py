@@ -80,6 +80,8 @@ def lib():
     _sig(L.fmgan_resize_bilinear_u8, [vp] * 4 + [i] * 5 + [f, f, vp])
     _sig(L.fmgan_tensor_to_images, [vp, vp, i, i, i, f, f, vp])
     _sig(L.fmgan_torgb_f32, [vp] * 6 + [i] * 4 + [f, vp])
+    _sig(L.fmgan_torgb_backward_splits, [i] * 3)
+    _sig(L.fmgan_torgb_backward_f32, [vp] * 6 + [i] * 4 + [f, vp])
     _sig(L.fmgan_refresh_entry_bytes, [])
     _sig(L.fmgan_weight_refresh_blocks, [i, i, i, i, ll], ll)
     _sig(L.fmgan_weight_refresh_f32, [vp, i, ll, vp])
@@ -500,6 +502,33 @@ def torgb(x, weight, style, bias, skip, scale):
                                     float(scale), stream), 'torgb')
         _observer.end(tok)
     return out
+
+
+def torgb_backward(x, grad_out, weight, style, scale):
+    """Data gradient of ToRGB's 1x1 modulated conv and the pixel contraction M[b,c,i] = sum_p grad_out[b,c,p]*x[b,i,p]
+    from one pass over x.  Returns (grad_x [B,cin,H,W], M [B,cout,cin]) or None when the kernel does not serve the
+    shape (H*W % 4 != 0, not f32)."""
+    require_gpu(x, 'input')
+    if x.dtype != torch.float32 or grad_out.dtype != torch.float32:
+        return None
+    x, go, style = x.contiguous(), grad_out.contiguous(), style.contiguous()
+    b, cin, h, w = x.shape
+    cout = weight.numel() // cin
+    splits = lib().fmgan_torgb_backward_splits(b, cin, h * w)
+    if splits == 0 or cout > 4:
+        return None
+    gx = torch.empty_like(x)
+    mpart = torch.empty((splits, b, cout, cin), dtype=torch.float32, device=x.device)
+    wgt = weight.contiguous()
+    with on_device(x) as stream:
+        tok = _observer.begin('torgb_backward', (b, cin, cout, h * w))
+        st = lib().fmgan_torgb_backward_f32(ptr(x), ptr(go), ptr(wgt), ptr(style), ptr(gx), ptr(mpart), b, cin, cout, h * w,
+                                            float(scale), stream)
+        _observer.end(tok)
+    if st == -2:
+        return None
+    check(st, 'torgb_backward')
+    return gx, (mpart.sum(0) if splits > 1 else mpart[0])
 
 
 def images_to_tensor(images, mean=0.5, std=0.5):

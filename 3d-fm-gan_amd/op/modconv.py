@@ -279,8 +279,19 @@ class ToRGBFunction(Function):
     def backward(ctx, grad_out):
         x, weight, s, bias = ctx.saved_tensors[:4]
         scale = ctx.scale
-        gx, gw, gs = _regrad(lambda a, b, c: modconv_composite(a, b, c, False, 0, scale), (x, weight, s),
-                             ctx.needs_input_grad[:3], grad_out)
+        both = None
+        if not torch.is_grad_enabled():      # plain backward: one pass over x on the HIP kernel
+            both = _native.torgb_backward(x, grad_out, weight, s, scale)
+        if both is not None:
+            gx, m = both                      # m[b,c,i] = sum_p grad_out[b,c,p] * x[b,i,p]
+            w2 = weight.reshape(-1, x.shape[1])
+            gw = (scale * (m * s[:, None, :]).sum(0)).view_as(weight) if ctx.needs_input_grad[1] else None
+            gs = scale * (m * w2[None]).sum(1) if ctx.needs_input_grad[2] else None
+            if not ctx.needs_input_grad[0]:
+                gx = None
+        else:                                 # graph requested (path-length regulariser) / unserved shape: composite
+            gx, gw, gs = _regrad(lambda a, b, c: modconv_composite(a, b, c, False, 0, scale), (x, weight, s),
+                                 ctx.needs_input_grad[:3], grad_out)
         gb = grad_out.sum([0, 2, 3]).view(bias.shape) if ctx.needs_input_grad[3] else None
         gk = grad_out if (ctx.has_skip and ctx.needs_input_grad[4]) else None
         return gx, gw, gs, gb, gk, None

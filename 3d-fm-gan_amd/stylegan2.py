@@ -18,7 +18,7 @@ from torch import nn, autograd
 from torch.nn import functional as F
 
 from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
-from op import _native, modconv
+from op import _native, conv_grad, modconv
 from op._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 from op.live_weights import LiveWeights, live
 from Util.streams import side_streams, run_on, overlap_ok
@@ -104,6 +104,10 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input):
+        if input.is_cuda and torch.is_grad_enabled():
+            # same convolution; its derivatives of every order are the library's backward-data / backward-weight
+            # primitives (op/conv_grad.py: PyTorch's generic conv double-backward costs R1 1.6 s per step at 1024^2)
+            return conv_grad.conv2d(input, self.weight * self.scale, self.bias, self.stride, self.padding)
         return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
 
     def __repr__(self):

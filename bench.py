@@ -57,6 +57,14 @@ WORKLOADS = {
                           desc='cfg5: train() iteration @1024^2, fp32, B=8/GPU: D(1024) loss + R1/16 + G adv + L1 + LPIPS('
                           'VGG16 topology, random init: load only) + ArcFace(resnet_face18 topology, random init: load only) '
                           '+ path length/4 on B/2 + EMA, Adam; DDP/RCCL all-reduce when N>1'),
+    # The same iteration with reduced-precision contractions — a LABELLED EXTENSION, never the headline (the reference
+    # trains in fp32; SURVEY §8c states 5e-2 on [-1,1] images for this configuration): torch.autocast(bf16) around the
+    # whole iteration (every MIOpen convolution / linear of the encoders, D and the loss networks in bf16; this repo's
+    # HIP ops cast their inputs back to fp32) and the modulated conv's forward / data-gradient contractions on
+    # v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulation; weight gradients and optimiser state stay fp32).
+    'trainstep1024_bf16': dict(size=1024, batch=8, loss_nets=True, precision='bf16',
+                               desc='cfg5, bf16 leg: trainstep1024 under torch.autocast(bfloat16) + bf16-operand / fp32-'
+                               'accumulate modulated conv (csrc/modconv_bf16.hip); fp32 master weights and optimiser'),
 }
 # the lazy regularisers recur every 16 (R1) and 4 (path length) iterations: any 16 consecutive iterations hold exactly
 # one R1 step and four path-length steps, so a timed window of 16 IS the amortised cost of an iteration
@@ -158,7 +166,7 @@ def make_train_step(nets, batch, device, rank, world):
     return step, (photo, render)
 
 
-def make_trainstep(nets, batch, device, rank, world, size, loss_nets=False):
+def make_trainstep(nets, batch, device, rank, world, size, loss_nets=False, precision='f32'):
     """A full training iteration (3d-fm-gan_amd/train_3_encoder.py::Trainer.step) on synthetic pairs."""
     import stylegan2
     import train_3_encoder as T
@@ -172,8 +180,15 @@ def make_trainstep(nets, batch, device, rank, world, size, loss_nets=False):
     tr = T.Trainer(dict(G=nets['g'], E_Tsr=nets['e_tsr'], E_W=nets['e_w'], E_W_Plus=nets['e_wp'], D=d),
                    T.default_args(rec_batch=batch), device, lpips_model=lp, face_rec_model=fr)
 
-    def step():
-        tr.step(photo, render, ref)
+    if precision == 'bf16':
+        from op import _native
+
+        def step():
+            with torch.autocast('cuda', dtype=torch.bfloat16), _native.modconv_precision('bf16'):
+                tr.step(photo, render, ref)
+    else:
+        def step():
+            tr.step(photo, render, ref)
 
     return step, tr
 
@@ -197,7 +212,7 @@ def train_leg(name, steps, world, timeout_s):
     import subprocess
     env = dict(os.environ)
     if world > 1:
-        env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + {'train256': 7, 'trainstep256': 13}.get(name, 19))
+        env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + {'train256': 7, 'trainstep256': 13, 'trainstep1024': 19}.get(name, 23))
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--workload', name, '--steps', str(steps),
            '--warmup', '2', '--no-cpu-baseline']
     log(f'{name}: child process, time box {timeout_s:.0f} s')
@@ -473,6 +488,12 @@ def main():
     # Forward workloads only: the exhaustive search over every backward-data / weight-gradient solver of the training
     # workload (it times MIOpen's naive reference kernels too) takes more than 7 minutes of warm-up.
     torch.backends.cudnn.benchmark = not args.workload.startswith('train')
+    if args.workload.startswith('train') and os.environ.get('FMGAN_TRAIN_FIND', '0') != '0':
+        # Opt-in: take MIOpen's MEASURED kernel choice for the training convolutions too, but never search inside a bench
+        # run — FAST find mode answers from the user find-db shipped in miopen_cache/ (filled once by
+        # tools/warm_miopen_cache.sh with FMGAN_TRAIN_FIND=search) and falls back to the immediate-mode heuristic on a miss.
+        torch.backends.cudnn.benchmark = True
+        os.environ.setdefault('MIOPEN_FIND_MODE', 'NORMAL' if os.environ['FMGAN_TRAIN_FIND'] == 'search' else 'FAST')
     if torch.backends.cudnn.benchmark:
         # the search otherwise also times MIOpen's naive reference convolutions — 2.5 s of GPU time per process that can
         # never win; leaving them out shortens the warm-up (the same kernels get picked).  Set before the first conv.
@@ -492,7 +513,8 @@ def main():
         else:
             for m in nets.values():
                 m.requires_grad_(True)
-            step, trainer = make_trainstep(nets, batch, device, rank, world, wl['size'], wl.get('loss_nets', False))
+            step, trainer = make_trainstep(nets, batch, device, rank, world, wl['size'], wl.get('loss_nets', False),
+                                           wl.get('precision', 'f32'))
         for i in range(args.warmup):
             step()
             torch.cuda.synchronize()
@@ -515,7 +537,7 @@ def main():
                           '(photo,render) pairs/sec (training iteration)', 'value': world * batch * args.steps / dt,
                 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'f32', 'data': 'synthetic',
+                'dtype': 'bf16 operands / f32 accumulate' if wl.get('precision') == 'bf16' else 'f32', 'data': 'synthetic',
                 'config': {'workload': f"{args.workload}: {wl['desc']}", 'pairs_per_gpu': batch, 'global_pairs': batch * world,
                            'image_size': wl['size'], 'parallelism': f'dp{world} (DDP, 256 MiB buckets)' if world > 1 else 'single GPU',
                            'phase_mix': mix, **dist_info(world)}}))
@@ -657,7 +679,7 @@ def main():
             # running this script with --workload: MIOpen has no pre-built kernels for gfx950 in this image and compiles
             # every backward convolution on first use — minutes on a fresh box (seconds once its cache is warm, see
             # warm_miopen_cache) — so the legs run inside a time box and the headline line is never held hostage by them.
-            for name in ('train256', 'trainstep256', 'trainstep1024'):
+            for name in ('train256', 'trainstep256', 'trainstep1024', 'trainstep1024_bf16'):
                 # a training iteration is timed over whole windows of 16 (one R1 step + four path-length steps each)
                 t_steps = TRAINSTEP_WINDOW if name.startswith('trainstep') else max(3, args.steps // 4)
                 rec = train_leg(name, t_steps, world, float(os.environ.get('FMGAN_BENCH_TRAIN_TIMEOUT', '480')))

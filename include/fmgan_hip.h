@@ -356,6 +356,23 @@ int fmgan_torgb_f32(const float *in, const float *weight, const float *style,
                     int batch, int cin, int cout, int hw, float scale, void *stream);
 
 /*
+ * Backward of ToRGB's modulated 1x1 conv in one pass over its input (the reference: autograd of a grouped F.conv2d,
+ * stylegan2.py:268-286 called from :389-404):
+ *   grad_x[b,i,p] = sum_c scale*weight[c,i]*style[b,i] * grad_out[b,c,p]
+ *   m_partial[s,b,c,i] = sum over the pixels of split s of grad_out[b,c,p] * x[b,i,p]
+ * x / grad_x [batch,cin,hw], grad_out [batch,cout,hw], weight [cout,cin], style [batch,cin], cout <= 4;
+ * m_partial [fmgan_torgb_backward_splits(batch,cin,hw), batch, cout, cin].  The caller sums m_partial over s (fixed order:
+ * bit-reproducible) to M[b,c,i] and forms grad_weight[c,i] = scale * sum_b style[b,i]*M[b,c,i],
+ * grad_style[b,i] = scale * sum_c weight[c,i]*M[b,c,i]; grad_bias and grad_skip are sums / copies of grad_out.
+ * hw % 4 == 0 and 16-byte aligned pointers, else FMGAN_EUNSUPPORTED (splits() returns 0): the caller differentiates the
+ * composite instead.
+ */
+int fmgan_torgb_backward_splits(int batch, int cin, int hw);
+int fmgan_torgb_backward_f32(const float *x, const float *grad_out, const float *weight, const float *style,
+                             float *grad_x, float *m_partial, int batch, int cin, int cout, int hw, float scale,
+                             void *stream);
+
+/*
  * The steps either side of the path, 3-channel images:
  *   fmgan_images_to_tensor: in uint8 [batch,h,w,3] -> out f32 [batch,3,h,w] = ((in/255) - mean) / std
  *       == transforms.ToTensor() + Normalize(mean, std) (train_3_encoder.py:233-239; Resize: fmgan_resize_* below)

@@ -7,6 +7,7 @@ import re
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 import cases
 import synth
@@ -103,6 +104,19 @@ def test_fused_bias_act_backward_host_logic():
     assert L.fmgan_fused_bias_act_bwd_f32(None, None, None, None, -1, 64, 0.2, 1.4, None) == -1
     assert L.fmgan_fused_bias_act_bwd_f32(16, 16, 16, 16, 4, 30, 0.2, 1.4, None) == -2              # unserved plane size
     assert L.fmgan_fused_bias_act_bwd_f32(20, 16, 16, 16, 4, 64, 0.2, 1.4, None) == -2              # misaligned
+
+
+def test_torgb_backward_host_logic():
+    L = _lib()
+    assert L.fmgan_torgb_backward_splits(8, 32, 1024 * 1024) >= 64          # enough blocks to fill the chip
+    assert L.fmgan_torgb_backward_splits(2, 512, 16) == 1
+    assert L.fmgan_torgb_backward_splits(2, 512, 18) == 0                   # H*W % 4 != 0: composite instead
+    assert L.fmgan_torgb_backward_splits(0, 512, 16) == 0
+    L.fmgan_torgb_backward_f32.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p]
+    assert L.fmgan_torgb_backward_f32(None, None, None, None, None, None, 0, 32, 3, 64, 1.0, None) == 0
+    assert L.fmgan_torgb_backward_f32(None, None, None, None, None, None, 2, 32, 3, 64, 1.0, None) == -1
+    assert L.fmgan_torgb_backward_f32(16, 16, 16, 16, 16, 16, 2, 32, 5, 64, 1.0, None) == -1     # cout > 4
+    assert L.fmgan_torgb_backward_f32(16, 16, 16, 16, 16, 16, 2, 32, 3, 66, 1.0, None) == -2
 
 
 def test_product_has_no_cpu_path():
@@ -267,3 +281,35 @@ def test_modconv_index_range_guards_refuse_without_launching():
     assert conv(1, 8, 8, 2, 2, 2) == EINVAL
     assert L.fmgan_modconv_wgrad_f32(fake, None, fake, fake, fake, 1, 8, 8, 46341, 46341, 1.0, fake, 1 << 30, None) == EOVER
     assert L.fmgan_modconv_wgrad_f32(fake, None, fake, fake, fake, 1, (1 << 20) + 1, 8, 32, 32, 1.0, fake, 1 << 30, None) == EOVER
+
+
+@pytest.mark.parametrize('geom', [(3, 1, 1), (3, 2, 0), (1, 2, 0), (1, 1, 0)])
+def test_conv_grad_family_matches_conv2d_autograd_at_every_order(geom):
+    """op/conv_grad.py: conv2d as three Functions that differentiate into each other (host logic, library primitives —
+    runs on CPU too).  First, second and third order agree with F.conv2d's own autograd on the Discriminator's four
+    geometries (3x3 pad 1; 3x3 stride 2; 1x1 stride 2; 1x1), in float64."""
+    from op import conv_grad
+    k, stride, pad = geom
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 9, 8, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 3, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(4, dtype=torch.float64, requires_grad=True)
+
+    def ours(x_, w_, b_):
+        return conv_grad.conv2d(x_, w_, b_, stride, pad)
+
+    def ref(x_, w_, b_):
+        return F.conv2d(x_, w_, b_, stride, pad)
+    assert torch.autograd.gradcheck(ours, (x, w, b))
+    assert torch.autograd.gradgradcheck(ours, (x, w, b))
+    # R1-shaped use: penalty on the input gradient, differentiated w.r.t. the weight — and once more
+    outs = []
+    for f in (ours, ref):
+        y = f(x, w, b)
+        gx, = torch.autograd.grad(y.pow(2).sum(), x, create_graph=True)
+        pen = gx.pow(2).sum()
+        gw, = torch.autograd.grad(pen, w, create_graph=True)
+        g3, = torch.autograd.grad(gw.pow(2).sum(), x)
+        outs.append((y.detach(), gx.detach(), gw.detach(), g3))
+    for a, c in zip(*outs):
+        torch.testing.assert_close(a, c, rtol=1e-10, atol=1e-10)

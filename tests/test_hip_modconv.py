@@ -176,6 +176,40 @@ def test_to_rgb_golden(c, golden):
     np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
 
 
+@pytest.mark.parametrize('cfg', [(2, 512, 4, 4, True), (3, 40, 8, 8, False), (2, 64, 32, 32, True), (1, 32, 256, 256, True),
+                                 (2, 17, 16, 20, True), (8, 32, 512, 512, False)])
+def test_torgb_backward_kernel_vs_float64_autograd(cfg):
+    """fmgan_torgb_backward_f32 (data gradient + pixel contraction in one pass) through ToRGBFunction.backward: all five
+    gradients vs float64 autograd of the differentiable composite (stylegan2.py:389-404 restated); two runs bit-equal."""
+    from op import modconv
+    b, cin, h, w, with_skip = cfg
+    d = dev()
+    x = synth.tensor(f'tb/{cfg}/x', (b, cin, h, w)).to(d).requires_grad_(True)
+    wgt = synth.tensor(f'tb/{cfg}/w', (1, 3, cin, 1, 1)).to(d).requires_grad_(True)
+    s = synth.tensor(f'tb/{cfg}/s', (b, cin), shift=1.0, scale=0.5).to(d).requires_grad_(True)
+    bias = synth.tensor(f'tb/{cfg}/b', (1, 3, 1, 1)).to(d).requires_grad_(True)
+    skip = synth.tensor(f'tb/{cfg}/k', (b, 3, h, w)).to(d).requires_grad_(True) if with_skip else None
+    go = synth.tensor(f'tb/{cfg}/go', (b, 3, h, w)).to(d)
+    scale = 1.0 / np.sqrt(cin)
+    ins = [x, wgt, s, bias] + ([skip] if with_skip else [])
+    assert _native_serves(b, cin, h * w)
+    g1 = torch.autograd.grad(modconv.to_rgb(x, wgt, s, bias, skip, scale), ins, go)
+    g2 = torch.autograd.grad(modconv.to_rgb(x, wgt, s, bias, skip, scale), ins, go)
+    for a, c in zip(g1, g2):
+        assert torch.equal(a, c)
+    ins64 = [t.detach().double().requires_grad_(True) for t in ins]
+    y64 = modconv._torgb_composite(ins64[0], ins64[1], ins64[2], ins64[3], ins64[4] if with_skip else None, scale)
+    ref = torch.autograd.grad(y64, ins64, go.double())
+    for name, a, r in zip(('x', 'weight', 'style', 'bias', 'skip'), g1, ref):
+        err = float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        assert err < 2e-5, (name, err)
+
+
+def _native_serves(b, cin, hw):
+    from op import _native
+    return _native.lib().fmgan_torgb_backward_splits(b, cin, hw) > 0
+
+
 def test_torgb_kernel_vs_c_oracle_ragged():
     from op import _native
     from oracle import c_oracle

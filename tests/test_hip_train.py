@@ -12,21 +12,28 @@ Tolerance rule for gradients.  The reference's fp32 CPU gradients themselves dif
 3e-2 of a tensor's max (L1's sign(), long reductions with cancellation), so a fixed relative tolerance vs the fp32
 fixture would be either vacuous or flaky.  Each tensor is therefore held to
       |hip - fp64|  <=  MARGIN * |ref_fp32 - fp64|  +  FLOOR * max|fp64|
-i.e. "no farther from the exact value than the reference itself, up to a small factor".  The floors are the measured
-worst cases (profiles/r02_parity_errors.md, tools/measure_parity.py) times ~3: tensors whose gradient this repo's
-kernels and torch reductions produce 1e-3 (measured 2.3e-4), encoder tensors whose weight gradients come from MIOpen's
-fp32 wgrad kernels 2e-2: those are not run-to-run reproducible and put isolated elements 1.3e-3 ... 6.2e-3 of the tensor's
-max away from the float64 value (resnet conv1.weight 2.0e-3, pSp head convs 1.3e-3 and 6.2e-3 in three runs of the same
-binary), while the tensors' norms agree to 4e-5 (checked with the tight norm floor).
+i.e. "no farther from the exact value than the reference itself, up to a small factor".  Floors, from measurement
+(profiles/r03_kink_experiment.md, profiles/r02_parity_errors.md, tools/measure_parity.py):
+  * Generator alone on fixture inputs (only this repo's kernels run): 2e-4, no exceptions (OWN_FLOOR; test below);
+  * Generator tensors inside the end-to-end path (its latents come from MIOpen encoders and carry their 1e-7 run-to-run
+    noise): FLOOR = 5e-4 — measured 2.3e-4 vs fp64 and 2.5e-4 run to run;
+  * encoder tensors (MIOpen fp32 wgrad kernels, not run-to-run reproducible): FLOOR_MIOPEN = 4e-3 — measured 2.0e-3 vs fp64
+    on resnet conv1.weight and 1.3e-3 on a pSp head conv, 5.7e-5 run to run when no unit flips; norms agree to 4e-5.
 
-Kinks.  Every network on the path has piecewise-linear units (LeakyReLU / PReLU / L1's sign).  MIOpen's forward convs are
-not run-to-run reproducible (1e-7, profiles/r02_determinism.md), so a pre-activation that lies within 1e-7 of zero takes
-the other slope in one run out of two.  With ~3e6 such units in the pSp heads about one flip per run is expected; in a
-2x2 or 4x4 feature map it moves one element of a bias gradient (a sum of B*H*W = 8 ... 32 terms) by a few per cent
-(observed: 6.2e-3, 2.2e-2 on different tensors of `e_wp/styles.*` in different runs, every other tensor unchanged).
-The reference's own fp32-vs-fp64 differences have the same cause.  A comparison therefore tolerates up to KINK_TENSORS
-tensors per backward pass beyond the floor, each by at most KINK_MAX of its max, and holds every other tensor (and the
-norms of all of them) to the rule above.
+Kinks — tested, not assumed (profiles/r03_kink_experiment.md: four runs in one process, 113 M piecewise-linear units
+recorded per run).  MIOpen's forward convs are not run-to-run reproducible (1.8e-6 of the image), and in EVERY pair of runs a
+handful of PReLU / LeakyReLU units of the pSp encoder (1-2 per affected site, |pre-activation| <= 1.2e-6 against site maxima
+of 3-6) land on the other side of zero.  Networks in which no unit flipped (both ResNets, all six pairs) agree to 5.7e-5
+run to run; the pSp encoder, with flips in all six pairs, shows 2-3 tensors per pair beyond 1e-3 and up to 1.5e-2 (head
+convs `styles.N.convs.0.weight`: 2x2 / 4x4 feature maps, where one unit is a visible fraction of a weight gradient).  The
+reference's own fp32-vs-fp64 differences have the same cause.  So:
+  * the allowance applies to ENCODER tensors only (prefix e_*); Generator tensors get none — flips inside G (3-5 units per
+    128^2-256^2 layer) move its gradients by 2.5e-4 at most, inside FLOOR;
+  * at most KINK_TENSORS tensors per backward pass may exceed the floor, each by at most KINK_MAX = 5e-2 of its max (3x the
+    largest observed) with its norm within KINK_NORM;
+  * and each such tensor must be UNSTABLE: the backward is run a second time and the tensor must either meet the floor there
+    or differ between the two HIP runs by more than a quarter of the floor.  A real kernel bug is persistent — both runs off
+    by the same amount — and fails this.
 """
 import os
 import sys
@@ -42,8 +49,8 @@ import synth
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-MARGIN, FLOOR, FLOOR_MIOPEN, FLOOR_NORM, FLOOR_SCALAR = 4.0, 1e-3, 2e-2, 5e-4, 8e-3
-KINK_TENSORS, KINK_MAX, KINK_NORM = 6, 0.1, 2e-2     # one flip shows in the weight AND the bias gradient of its layer
+MARGIN, FLOOR, FLOOR_MIOPEN, FLOOR_NORM, FLOOR_SCALAR = 4.0, 5e-4, 4e-3, 5e-4, 8e-3
+KINK_TENSORS, KINK_MAX, KINK_NORM = 6, 5e-2, 2e-2     # one flip shows in the weight AND the bias gradient of its layer
 
 
 def dev():
@@ -92,7 +99,9 @@ def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=None,
     worst = 0.0
     auto_floor = floor is None
     if auto_floor:
-        floor = FLOOR_MIOPEN if prefix.split('/')[-1].startswith('e_') else FLOOR
+        net = prefix.split('/')[-1]
+        # the Discriminator's weight gradients are MIOpen's too; measured inside 1e-3 (round 2 gate, kept)
+        floor = FLOOR_MIOPEN if net.startswith('e_') else (1e-3 if net == 'd' else FLOOR)
     for name, p in named_params:
         key = f'{prefix}/{name}'
         if key + '/s' not in g.files:
@@ -115,17 +124,36 @@ def check_grads(g, prefix, named_params, report=None, margin=MARGIN, floor=None,
             # relative error of the upstream gradient amplified by that cancellation.  Measured 2.0e-3 (reference 1e-4).
             fl = fn = FLOOR_SCALAR
         over = e_hip > margin * e_ref + fl or en_hip > margin * en_ref + fn
-        if kinks is not None and over and e_hip <= KINK_MAX and en_hip <= margin * en_ref + KINK_NORM:
+        encoder = prefix.split('/')[-1].startswith('e_')
+        if kinks is not None and encoder and over and e_hip <= KINK_MAX and en_hip <= margin * en_ref + KINK_NORM:
             # (a flipped unit of a tiny layer — an SE gate's ReLU has B x C/16 outputs — moves a whole row of the weight
             # gradient: the strided sample may miss it while the norm shows it, e.g. ppl/e_wp/body.0.res_layer.5.fc1.weight
             # norm 1.3e-3 off in one run)
-            kinks.append((key, e_hip, en_hip))
+            kinks.append((key, e_hip, en_hip, s.copy(), nrm, margin * e_ref + fl, margin * en_ref + fn, scale, s64, n64))
         else:
             assert e_hip <= margin * e_ref + fl, f'{key}: sample err {e_hip:.3e} vs reference-fp32 err {e_ref:.3e}'
             assert en_hip <= margin * en_ref + fn, f'{key}: norm err {en_hip:.3e} vs reference-fp32 err {en_ref:.3e}'
         worst = max(worst, e_hip)
         n += 1
     return n, worst
+
+
+def confirm_kinks(kinks, rerun):
+    """The second half of the kink rule: `rerun()` repeats the backward and returns {fixture key: parameter}.  Every
+    tensor that was admitted as a kink must meet its floor in the second run or differ between the two runs by more than
+    a quarter of its tolerance — a persistent deviation (a bug) does neither."""
+    assert len(kinks) <= KINK_TENSORS, [k[:3] for k in kinks]
+    if not kinks:
+        return
+    params = rerun()
+    for key, e1, en1, s1, n1, tol, tol_n, scale, s64, n64 in kinks:
+        s2, n2 = cases.grad_sample(params[key].grad)
+        e2 = float(np.abs(s2 - s64).max()) / scale
+        en2 = abs(n2 - n64) / max(n64, 1e-30)
+        moved = float(np.abs(s2 - s1).max()) / scale
+        moved_n = abs(n2 - n1) / max(n64, 1e-30)
+        ok = (e2 <= tol and en2 <= tol_n) or moved > 0.25 * tol or moved_n > 0.25 * tol_n
+        assert ok, f'{key}: off by {e1:.2e} (norm {en1:.2e}) in BOTH runs (moved {moved:.1e}): persistent, not a kink'
 
 
 def run_e2e_grad(report=None):
@@ -165,7 +193,11 @@ def test_cfg3_forward_backward_golden(golden):
     for k, m in nets.items():
         n, _ = check_grads(g, k, m.named_parameters(), kinks=kinks)
         total += n
-    assert len(kinks) <= KINK_TENSORS, kinks
+
+    def rerun():
+        nets2, _, _ = run_e2e_grad()
+        return {f'{k}/{n_}': p for k, m in nets2.items() for n_, p in m.named_parameters()}
+    confirm_kinks(kinks, rerun)
     assert total == len([k for k in g.files if k.endswith('/n64')])     # every fixture tensor was compared
     assert nets['g'].style[1].weight.grad is None                       # mapping network unused (input_is_latent)
 
@@ -235,10 +267,11 @@ def test_generator_only_backward_own_kernels_tight(golden):
 
 @pytest.mark.parametrize('own_wgrad', [False, True])
 def test_generator_only_backward_is_bit_reproducible(own_wgrad, monkeypatch):
-    """Two runs in one process.  Default configuration: every gradient this repo's kernels produce is bit-identical; the
-    weight gradients of the six upsampling convs come from MIOpen's stride-2 fp32 wgrad (op/modconv.py HIP_WGRAD = 1:
-    its kernels are faster there and not run-to-run reproducible) and agree to rounding.  With HIP_WGRAD = 2 (own
-    stride-2 wgrad kernel) all 93 tensors are bit-identical and still meet the tight gate."""
+    """Two runs in one process.  Every gradient this repo's kernels produce is bit-identical (ToRGB included since its
+    backward moved from the autograd composite to fmgan_torgb_backward_f32).  One family comes from library kernels that
+    are not run-to-run reproducible and agrees to rounding only: in the default configuration the weight gradients of the
+    six upsampling convs (MIOpen's stride-2 fp32 wgrad, op/modconv.py HIP_WGRAD = 1: faster there than the own kernel).
+    With HIP_WGRAD = 2 they join the bit-identical set and all 93 tensors still meet the tight gate."""
     from op import modconv
     if own_wgrad:
         monkeypatch.setattr(modconv, 'HIP_WGRAD', 2)
@@ -254,13 +287,17 @@ def test_generator_only_backward_is_bit_reproducible(own_wgrad, monkeypatch):
     G2, img2, _, _ = run_generator_only()
     assert torch.equal(img1, img2)
     miopen = {f'convs.{i}.conv.weight' for i in range(0, 12, 2)}       # transposed convs of Generator(256)
+    exact = 0
     for n, p in G2.named_parameters():
         if p.grad is None:
             continue
-        if n in miopen and not own_wgrad:
+        library = n in miopen and not own_wgrad
+        if library:
             torch.testing.assert_close(p.grad, g1[n], atol=2e-5 * float(g1[n].abs().max()), rtol=0)
         else:
             assert torch.equal(p.grad, g1[n]), n
+            exact += 1
+    assert exact == (93 if own_wgrad else 93 - 6)
 
 
 class FixedProbe:
@@ -313,6 +350,13 @@ def run_phase(phase, nets, args, photo, render, ref, probe, ppl_idx):
     return ld
 
 
+def _rerun_phase(phase, nets, photo, render, ref, probe, c):
+    for m in nets.values():
+        m.zero_grad(set_to_none=True)
+    run_phase(phase, nets, train_args(), photo, render, ref, probe, c['ppl_idx'])
+    return {f'{phase}/{k}/{n}': p for k, m in nets.items() for n, p in m.named_parameters()}
+
+
 @pytest.mark.parametrize('phase', ['d', 'r1', 'g', 'ppl'])
 @pytest.mark.parametrize('case', ['train_step', 'train_step_1024'])
 def test_train_step_phase_golden(case, phase, golden):
@@ -342,7 +386,7 @@ def test_train_step_phase_golden(case, phase, golden):
         for k in ('g', 'e_tsr', 'e_w', 'e_wp'):
             n, _ = check_grads(g, 'g/' + k, nets[k].named_parameters(), kinks=kinks)
             assert n > 20
-        assert len(kinks) <= KINK_TENSORS, kinks
+        confirm_kinks(kinks, lambda: _rerun_phase(phase, nets, photo, render, ref, probe, c))
         assert all(p.grad is None for p in nets['d'].parameters())       # D frozen
     else:
         np.testing.assert_allclose(ld['lengths'].detach().cpu().numpy(), g['ppl/lengths64'], rtol=1e-3)
@@ -353,7 +397,7 @@ def test_train_step_phase_golden(case, phase, golden):
             # convs.7.conv.modulation.weight (reference fp32: 4e-5) -> floor 3e-3 for G, the MIOpen floor for encoders
             n, _ = check_grads(g, 'ppl/' + k, nets[k].named_parameters(), floor=3e-3 if k == 'g' else None, kinks=kinks)
             assert n > 20
-        assert len(kinks) <= KINK_TENSORS, kinks
+        confirm_kinks(kinks, lambda: _rerun_phase(phase, nets, photo, render, ref, probe, c))
 
 
 def test_trainer_iteration_runs_and_updates_everything():

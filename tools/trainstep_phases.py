@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase time of one training iteration (GPU box):  python tools/trainstep_phases.py {256|1024} [batch] [reps]
+"""Per-phase time of one training iteration (GPU box):  python tools/trainstep_phases.py {256|1024} [batch] [reps] [bf16]
 
 Times D_Loss_BackProp, D_Reg_BackProp (R1), G_Loss_BackProp, G_Reg_BackProp (path length) and the EMA separately
 (synchronised around each), the way bench.py's trainstep workloads build them, and prints the lazy-regularisation
@@ -24,6 +24,7 @@ def main():
     wl = bench.WORKLOADS[name]
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else wl['batch']
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    bf16 = len(sys.argv) > 4 and sys.argv[4] == 'bf16'
     bench.warm_miopen_cache()
     import train_3_encoder as T
     from Util.training_util import accumulate
@@ -31,7 +32,7 @@ def main():
     nets = bench.build_models(size, d)
     for m in nets.values():
         m.requires_grad_(True)
-    step, tr = bench.make_trainstep(nets, batch, d, 0, 1, size, wl.get('loss_nets', False))
+    step, tr = bench.make_trainstep(nets, batch, d, 0, 1, size, wl.get('loss_nets', False), 'bf16' if bf16 else 'f32')
     gen = torch.Generator(device='cpu').manual_seed(1234)
     photo = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(d)
     render = (torch.rand(batch, 3, 256, 256, generator=gen) * 2 - 1).to(d)
@@ -46,6 +47,16 @@ def main():
         'PPL': lambda: T.G_Reg_BackProp(G, E_Tsr, E_W, E_W_Plus, photo, render, a, 0, tr.g_enc_optim),
         'EMA': lambda: accumulate(tr.g_ema, tr.bare['G'], tr.accum),
     }
+    if bf16:
+        from op import _native
+
+        def reduced(fn):
+            def run():
+                with torch.autocast('cuda', dtype=torch.bfloat16), _native.modconv_precision('bf16'):
+                    return fn()
+            return run
+        phases = {k: reduced(v) for k, v in phases.items()}
+        name += '_bf16'
     only = os.environ.get('PHASES')          # e.g. PHASES=R1 under rocprofv3: that phase alone, no 16-iteration window
     if only:
         phases = {k: v for k, v in phases.items() if k in only.split(',')}
