@@ -924,6 +924,26 @@ extern "C" int fmgan_blur_noise_bias_act_path_f32(const float* input, const floa
   return launch_rowmarch(input, kernel, out, p, (hipStream_t)stream, &ep, force_path);
 }
 
+// Which kernel fmgan_blur_noise_bias_act_f32 would run for these arguments (host logic, nothing is launched):
+// 5 = LDS-DMA ring (path 1b), 1 = register row-march (path 1), 2 = plane-tile, FMGAN_EUNSUPPORTED = none.
+extern "C" int fmgan_blur_noise_bias_act_select(const float* input, const float* out, const float* noise, int batch,
+                                                int channels, int in_h, int in_w, long long in_plane_stride,
+                                                int in_row_stride, int kernel_h, int kernel_w, int pad_x0, int pad_x1,
+                                                int pad_y0, int pad_y1) {
+  if (batch <= 0 || channels <= 0) return FMGAN_EINVAL;
+  const long long major = (long long)batch * channels;
+  if (major > 0x7fffffffLL) return FMGAN_EOVERFLOW;
+  int st = validate(FMGAN_F32, (int)major, in_h, in_w, 1, kernel_h, kernel_w, 1, 1, 1, 1);
+  if (st != FMGAN_OK) return st;
+  UfdParams p{(int)major, in_h, in_w, 1, kernel_h, kernel_w, 1, 1, 1, 1, pad_x0, pad_y0, 0, 0, in_plane_stride,
+              in_row_stride};
+  fmgan_upfirdn2d_out_size(in_h, in_w, kernel_h, kernel_w, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, &p.out_h, &p.out_w);
+  if (p.out_h <= 0 || p.out_w <= 0) return FMGAN_EINVAL;
+  UfdEpilogue ep{noise, nullptr, nullptr, channels, 1, 0.f, 1.f};
+  if (rowmarch_ok(FMGAN_F32, p)) return dmaring_ok(input, out, p, &ep) ? 5 : 1;
+  return planetile_ok(FMGAN_F32, p) ? 2 : FMGAN_EUNSUPPORTED;
+}
+
 extern "C" int fmgan_blur_noise_bias_act_f32(const float* input, const float* kernel, float* out, int batch,
                                              int channels, int in_h, int in_w, long long in_plane_stride,
                                              int in_row_stride, int kernel_h, int kernel_w, int pad_x0, int pad_x1,

@@ -49,6 +49,7 @@ def lib():
     _sig(L.fmgan_upfirdn2d, [i, vp, vp, vp] + [i] * 15 + [vp])
     _sig(L.fmgan_upfirdn2d_strided, [i, vp, vp, vp] + [i] * 4 + [ll, i] + [i] * 11 + [vp])
     _sig(L.fmgan_blur_noise_bias_act_f32, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6 + [vp] * 3 + [i, f, f, vp])
+    _sig(L.fmgan_blur_noise_bias_act_select, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6)
     _sig(L.fmgan_blur_noise_bias_act_path_f32, [vp] * 3 + [i] * 4 + [ll, i] + [i] * 6 + [vp] * 3 + [i, f, f, i, vp])
     _sig(L.fmgan_fused_bias_act, [i, vp, vp, vp, vp, ll, i, i, i, i, f, f, vp])
     _sig(L.fmgan_noise_bias_act_f32, [vp] * 5 + [i] * 4 + [f, f, vp])
@@ -133,8 +134,12 @@ class on_device:
 
 
 # ----------------------------------------------------------------------------- launch observer (bench.py)
+BLUR_PATHS = {}      # (planes, in_h, in_w) -> kernel id of the last fused blur of that shape, while an observer asks
+
+
 class _NullObserver:
     """bench.py installs an observer that brackets selected launches with HIP events on the launch stream."""
+    wants_paths = False
 
     def begin(self, name, info):
         return None
@@ -199,7 +204,7 @@ def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_strid
 
 
 def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_stride, row_stride, kernel, pad, noise,
-                        noise_weight, bias, alpha, scale, force_path=-1):
+                        noise_weight, bias, alpha, scale, force_path=-1, out=None):
     """blur -> (+noise) -> +bias -> lrelu*scale in one pass over a strided f32 input; returns [B,C,out_h,out_w] or None
     when neither the row-march kernels (out_w >= 64) nor the plane-tile kernel (planes up to ~110^2) serve the shape
     (the caller then uses the two-pass form)."""
@@ -209,8 +214,14 @@ def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_strid
     out_h, out_w = upfirdn2d_out_size(in_h, in_w, kh, kw, 1, 1, 1, 1, pad0, pad1, pad0, pad1)
     if out_w <= 0 or out_h <= 0:
         return None
-    out = torch.empty((batch, channels, out_h, out_w), dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty((batch, channels, out_h, out_w), dtype=torch.float32, device=device)
+    elif tuple(out.shape) != (batch, channels, out_h, out_w) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise RuntimeError('blur_noise_bias_act: `out` must be a contiguous f32 [B,C,out_h,out_w] tensor')
     nz = noise.contiguous() if noise is not None else None
+    if getattr(_observer, 'wants_paths', False):
+        BLUR_PATHS[(batch * channels, in_h, in_w)] = lib().fmgan_blur_noise_bias_act_select(
+            in_ptr, ptr(out), ptr(nz), batch, channels, in_h, in_w, plane_stride, row_stride, kh, kw, pad0, pad1, pad0, pad1)
     with on_device(out) as stream:
         tok = _observer.begin('upfirdn2d', (batch * channels, in_h, in_w, out_h, out_w, 1, 1, 4))
         st = lib().fmgan_blur_noise_bias_act_path_f32(in_ptr, ptr(k), ptr(out), batch, channels, in_h, in_w,
@@ -345,6 +356,13 @@ def modconv_weight_prep(weight, scale, kind=0):
         check(lib().fmgan_modconv_weight_prep_f32(ptr(weight), ptr(wt), cout, cin, kh * kw, float(scale), int(kind),
                                                   stream), 'modconv_weight_prep')
     return wt
+
+
+def aligned_rows_shape(b, c, oh, ow, pad0):
+    """(storage shape, element offset of logical (0,0,0,0), plane stride, row stride) of aligned_rows_buffer."""
+    off = pad0 % 4
+    rs = (ow + off + 31) // 32 * 32
+    return (b * c, oh, rs), off, oh * rs, rs
 
 
 def aligned_rows_buffer(b, c, oh, ow, pad0, device):

@@ -1,0 +1,116 @@
+"""Placement-selected persistent workspaces for the largest streaming pairs of the inference forward.
+
+Measured on MI355X (profiles/r03_bimodal_probe.md, profiles/r03_block_speed_probe.md): a streaming kernel that reads one
+~1 GB buffer and writes another runs at one of two rates depending on WHICH two device allocations it was handed — the
+fused 1024^2 blur: ~4.85 TB/s or ~5.17 TB/s.  The allocations of a process fall into two classes; a (read, write) pair from
+the SAME class is slow, a pair from DIFFERENT classes is fast, in both directions (a symmetric, XOR-like relation — what a
+high-order physical address bit in the DRAM channel / bank hash produces: same class = read and write streams contend for
+the same bank groups).  Every block alone reads and writes at the same rate, virtual addresses do not predict the class,
+and a process's caching allocator hands the two buffers of a layer to arbitrary cached blocks — hence round 2's "bimodal
+between launches" in-step rate of the headline blur (0.58 or 0.64 of the HBM roofline).
+
+User code can neither read nor choose physical placement.  It can MEASURE: for the few layers whose intermediate is large
+enough to matter, the no_grad forward keeps a persistent (intermediate, output) pair, chosen once — candidates are
+allocated one at a time and timed on the layer's real producer + blur launches until both classes have been seen (or a cap
+is reached), the fastest pair is kept, the rest is released.  The buffers are private to one module, one shape and one
+stream; they never leave the synthesis network (its only output is the ToRGB image), so reuse across forwards is ordered
+by the stream.  FMGAN_PLACEMENT=0 disables it.
+"""
+import os
+import weakref
+
+import torch
+
+ENABLED = os.environ.get('FMGAN_PLACEMENT', '1') != '0'
+MIN_BYTES = 256 << 20        # intermediates smaller than this fit the 256 MiB Infinity Cache: no placement effect measured
+MAX_CANDIDATES = 6           # blocks tried per role before settling for the best pair seen
+CONTRAST = 1.03              # both classes seen once the fastest pair beats the slowest by 3 % (the classes differ by 6-7 %)
+
+_STORE = weakref.WeakKeyDictionary()     # module -> {key: workspace}; never deep-copied, never in a state_dict
+_depth = 0
+
+
+class scope:
+    """Entered by a network's inference forward: inside, a layer may hand out persistent workspaces, because its output
+    is consumed before the forward returns.  A layer called on its own (outside any scope) always allocates fresh
+    tensors — its caller may keep them across calls."""
+
+    def __enter__(self):
+        global _depth
+        _depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _depth
+        _depth -= 1
+        return False
+
+
+def active():
+    return ENABLED and _depth > 0
+
+
+class Workspace:
+    __slots__ = ('buf', 'out', 'rate', 'tried')
+
+    def __init__(self, buf, out, rate, tried):
+        self.buf, self.out, self.rate, self.tried = buf, out, rate, tried
+
+
+def _time(produce, consume, buf, out, reps=3):
+    """Fastest of `reps` consumer launches, each right after its producer (as in a step); only the consumer is timed."""
+    best = None
+    for _ in range(reps):
+        produce(buf)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        consume(buf, out)
+        b.record()
+        b.synchronize()
+        t = a.elapsed_time(b)
+        best = t if best is None else min(best, t)
+    return best
+
+
+def workspace(owner, key, buf_shape, out_shape, device, produce, consume):
+    """The persistent (intermediate, output) pair of `owner` for `key` on the current stream.
+    produce(buf) launches the layer's producer into `buf`, consume(buf, out) its streaming consumer (values are
+    irrelevant while probing).  Selection happens on the first call and costs a few launches of the pair."""
+    per = _STORE.setdefault(owner, {})
+    key = (key, torch.cuda.current_stream(device).cuda_stream)
+    ws = per.get(key)
+    if ws is not None:
+        return ws
+    if torch.cuda.is_current_stream_capturing():
+        return None          # selection needs timed launches: not inside a HIP-graph capture (warm up eagerly first)
+    # out candidates are tried against buf candidate 0, then buf candidates against the best out: the relation is
+    # symmetric and two-class, so this finds a cross-class pair as soon as one of each class exists among the candidates
+    bufs = [torch.empty(buf_shape, dtype=torch.float32, device=device)]
+    outs, rates = [], []
+    for _ in range(MAX_CANDIDATES):
+        outs.append(torch.empty(out_shape, dtype=torch.float32, device=device))
+        rates.append(_time(produce, consume, bufs[0], outs[-1]))      # (times: smaller is faster)
+        if len(rates) > 1 and max(rates) >= min(rates) * CONTRAST:
+            break          # both classes seen
+    j = min(range(len(rates)), key=rates.__getitem__)
+    best = (0, j, rates[j])
+    if len(rates) == MAX_CANDIDATES and max(rates) < min(rates) * CONTRAST:
+        # every output candidate is in one class relative to buf 0: look for an intermediate of the other class
+        for _ in range(MAX_CANDIDATES - 1):
+            bufs.append(torch.empty(buf_shape, dtype=torch.float32, device=device))
+            t = _time(produce, consume, bufs[-1], outs[j])
+            if t < best[2]:
+                best = (len(bufs) - 1, j, t)
+            if t * CONTRAST <= rates[j]:
+                break
+    ws = Workspace(bufs[best[0]], outs[best[1]], best[2], len(bufs) + len(outs))
+    per[key] = ws
+    return ws
+
+
+def forget(owner=None):
+    """Drop the workspaces of one module (or all): the next forward selects again."""
+    if owner is None:
+        _STORE.clear()
+    else:
+        _STORE.pop(owner, None)

@@ -18,7 +18,7 @@ from torch import nn, autograd
 from torch.nn import functional as F
 
 from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
-from op import _native, conv_grad, modconv
+from op import _native, conv_grad, modconv, placement
 from op._native import amp_fwd as _amp_fwd, amp_bwd as _amp_bwd
 from op.live_weights import LiveWeights, live
 from Util.streams import side_streams, run_on, overlap_ok
@@ -323,16 +323,36 @@ class StyledConv(nn.Module):
             # 16-byte aligned (the contiguous 2W+1-float rows never are)
             c = conv.out_channel
             pad0, pad1 = conv.blur.pad
-            buf, p0, ps, rs = _native.aligned_rows_buffer(b, c, 2 * h + 1, 2 * w + 1, pad0, input.device)
-            _native.modconv2d(input, conv.mfma_weight(), s, demod, 1, strided_out=(p0, ps, rs))
-            out = _native.blur_noise_bias_act(p0, input.device, b, c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
-                                              (pad0, pad1), noise, self.noise.weight, act.bias, act.negative_slope,
-                                              act.scale)          # blur + noise + bias + act in the blur's store:
-            # row-march / LDS-DMA ring for planes >= 64 wide, plane-tile (whole planes in LDS) for the 8^2..32^2 layers
-            if out is None:   # shapes neither kernel serves (planes > ~110^2 narrower than 64): two passes
-                out = _native.upfirdn2d_strided(p0, input.device, b * c, 2 * h + 1, 2 * w + 1, ps, rs, conv.blur.kernel,
-                                                pad0, pad1, pad0, pad1).view(b, c, oh, ow)
-                out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)
+            shape, off, ps, rs = _native.aligned_rows_shape(b, c, 2 * h + 1, 2 * w + 1, pad0)
+            wt = conv.mfma_weight()
+
+            def produce(buf_):
+                _native.modconv2d(input, wt, s, demod, 1, strided_out=(buf_.data_ptr() + 4 * off, ps, rs))
+
+            def consume(buf_, out_):
+                # blur + noise + bias + act in the blur's store: row-march / LDS-DMA ring for planes >= 64 wide,
+                # plane-tile (whole planes in LDS) for the 8^2..32^2 layers
+                return _native.blur_noise_bias_act(buf_.data_ptr() + 4 * off, input.device, b, c, 2 * h + 1, 2 * w + 1, ps, rs,
+                                                   conv.blur.kernel, (pad0, pad1), noise, self.noise.weight, act.bias,
+                                                   act.negative_slope, act.scale, out=out_)
+            nbytes = 4 * shape[0] * shape[1] * shape[2]
+            ws = None
+            if placement.active() and nbytes >= placement.MIN_BYTES:
+                # the largest buffers of the forward: a persistent pair whose placement was selected by measurement
+                # (op/placement.py: the same kernel runs at 4.85 or 5.17 TB/s depending on which two blocks it gets)
+                ws = placement.workspace(self, (b, c, h, w), shape, (b, c, oh, ow), input.device, produce, consume)
+            if ws is not None:
+                buf, out = ws.buf, ws.out
+                produce(buf)
+                consume(buf, out)
+            else:
+                buf = torch.empty(shape, dtype=torch.float32, device=input.device)
+                produce(buf)
+                out = consume(buf, None)
+                if out is None:   # shapes neither kernel serves (planes > ~110^2 narrower than 64): two passes
+                    out = _native.upfirdn2d_strided(buf.data_ptr() + 4 * off, input.device, b * c, 2 * h + 1, 2 * w + 1, ps,
+                                                    rs, conv.blur.kernel, pad0, pad1, pad0, pad1).view(b, c, oh, ow)
+                    out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)
             del buf
         else:
             out = _native.modconv2d(input, conv.mfma_weight(), s, demod, 0, noise=noise,
@@ -487,7 +507,7 @@ class Generator(nn.Module):
         if (not torch.is_grad_enabled()) and self.input.input.is_cuda:
             if self._live_weights is None:
                 self._live_weights = LiveWeights(self)
-            with self._live_weights.fresh():
+            with self._live_weights.fresh(), placement.scope():
                 return self._forward(*args, **kwargs)
         return self._forward(*args, **kwargs)
 

@@ -84,6 +84,8 @@ class LaunchTimer:
     """HIP events on the launch stream (torch's current stream IS the stream _native launches on) around the
     launches selected by `want`; times are read after the region has been synchronised."""
 
+    wants_paths = True      # _native records which kernel served each fused blur (roofline.kernel names what ran)
+
     def __init__(self, want):
         self.want = want
         self.pairs = []
@@ -592,7 +594,11 @@ def main():
         if batch == wl['batch'] and args.workload == 'pairs1024':
             traffic, traffic_src = committed_traffic()
 
-        out['roofline'] = {'bound': 'hbm', 'kernel': f'ufd_dmaring_f32<true> (blur + fused noise/bias/lrelu store, LDS-DMA row ring) [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
+        path = _native.BLUR_PATHS.get((head[0], head[1], head[2]))
+        kname = {5: 'ufd_dmaring_f32<true> (blur + fused noise/bias/lrelu store, LDS-DMA row ring, path 1b)',
+                 1: 'ufd_rowmarch_f32 (blur + fused noise/bias/lrelu store, register row-march, path 1)',
+                 2: 'ufd_planetile_f32<true> (blur + fused epilogue, plane-tile)'}.get(path, f'upfirdn2d path {path}')
+        out['roofline'] = {'bound': 'hbm', 'kernel': f'{kname} [{head[0]},{head[1]},{head[2]}]->[{head[0]},{head[3]},{head[4]}]',
                            'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                            'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': ms, 'launches': n,
                            'algorithmic_bytes': bytes_alg}

@@ -118,6 +118,14 @@ int fmgan_blur_noise_bias_act_f32(const float *input, const float *kernel, float
                                   int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                   const float *noise, const float *noise_weight, const float *bias,
                                   int noise_batch, float alpha, float act_scale, void *stream);
+/* Which kernel serves a fused-blur call with these arguments (host logic, nothing is launched): 5 = LDS-DMA ring
+ * (path 1b), 1 = register row-march (path 1), 2 = plane-tile, FMGAN_EUNSUPPORTED = none.  bench.py names the kernel of
+ * its roofline object from this. */
+int fmgan_blur_noise_bias_act_select(const float *input, const float *out, const float *noise,
+                                     int batch, int channels, int in_h, int in_w,
+                                     long long in_plane_stride, int in_row_stride,
+                                     int kernel_h, int kernel_w,
+                                     int pad_x0, int pad_x1, int pad_y0, int pad_y1);
 /* The same with the row-march variant chosen by the caller (tests, measurements): force_path -1 / 1 automatic,
  * 4 = register row-march (path 1), 5 = LDS-DMA ring (path 1b; FMGAN_EUNSUPPORTED when its alignment rules do not hold).
  * Both variants produce the same bits.  fmgan_upfirdn2d(_strided) accept the same two values. */

@@ -375,3 +375,42 @@ def test_full_path_is_bit_reproducible_once_encoder_outputs_are_fixed():
             streams.ENABLED = True
         for _ in range(4):
             assert torch.equal(fwd(sliced), serial)
+
+
+def test_placement_workspaces_do_not_change_results_or_leak(monkeypatch):
+    """op/placement.py: the persistent, placement-selected (intermediate, output) pairs of the large upsampling layers.
+    Same bits as with fresh allocations; the image returned is always a fresh tensor and survives the next forward; a
+    layer called on its own never hands out a persistent tensor; selection happened for exactly the layers above 256 MiB."""
+    import stylegan2
+    from op import placement
+    G = stylegan2.Generator(256, 512, 2)
+    G.load_state_dict(synth.state_dict('generator', G.state_dict(), seed=4))
+    G = G.to(dev()).eval()
+    b = 32
+    lat = synth.tensor('pl/lat', (b, G.n_latent, 512)).to(dev())
+    lat2 = synth.tensor('pl/lat2', (b, G.n_latent, 512)).to(dev())
+    tsr = synth.tensor('pl/tsr', (b, 512, 4, 4)).to(dev())
+    kw = dict(input_is_latent=True, use_external_input_tensor=True, external_input_tensor=tsr, randomize_noise=False)
+    placement.forget()
+    with torch.no_grad():
+        monkeypatch.setattr(placement, 'ENABLED', False)
+        ref = G(None, latent_styles=[lat], **kw)
+        ref2 = G(None, latent_styles=[lat2], **kw)
+        monkeypatch.setattr(placement, 'ENABLED', True)
+        img = G(None, latent_styles=[lat], **kw)
+        keep = img.clone()
+        img2 = G(None, latent_styles=[lat2], **kw)
+    assert torch.equal(img, ref) and torch.equal(img2, ref2)
+    assert img.data_ptr() != img2.data_ptr() and torch.equal(img, keep)       # the first image was not overwritten
+    owners = [m for m in G.modules() if m in placement._STORE]
+    sizes = sorted(ws.buf.numel() * 4 for m in owners for ws in placement._STORE[m].values())
+    assert len(sizes) == 3 and sizes[0] >= placement.MIN_BYTES, sizes         # the 64^2, 128^2 and 256^2 upsampling layers
+    assert all(2 <= ws.tried <= 2 * placement.MAX_CANDIDATES for m in owners for ws in placement._STORE[m].values())
+    # a StyledConv called directly (no network scope) returns fresh tensors
+    sc = G.convs[-2]
+    x = synth.tensor('pl/x', (b, sc.conv.in_channel, 128, 128)).to(dev())
+    with torch.no_grad():
+        y1 = sc(x, lat[:, 0])
+        y2 = sc(x * 0.5, lat[:, 0])
+    assert y1.data_ptr() != y2.data_ptr() and not torch.equal(y1, y2)
+    placement.forget()
