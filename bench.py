@@ -313,7 +313,9 @@ def cpu_baseline(nets, inputs, size, budget_s=20.0):
             if time.perf_counter() - t0 > budget_s or n >= 16:
                 break
     dt = time.perf_counter() - t0
-    out = dict(value=n / dt, unit='pairs/s', cores=cores, kind='port', cpu_model=cpu_model(),
+    out = dict(value=n / dt, unit='pairs/s', cores=cores, cores_present=os.cpu_count(),
+               cores_note='threads used = the CPU share of a one-GPU box (cgroup quota / affinity, capped at 16); the '
+                          'socket has more cores than this process may use', kind='port', cpu_model=cpu_model(),
                sample=f'{n} pairs at B=1 through oracle/torch_oracle.py (reference CPU path restated: F.conv2d '
                       f'modconv + upfirdn2d_native + CPU fused_leaky_relu), Generator({size}), {dt:.1f} s')
     out['items'] = cpu_baseline_items(sds, photo, render, size)
