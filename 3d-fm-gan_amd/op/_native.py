@@ -114,6 +114,18 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def fp(t):
+    """data_ptr of an optional float32 GPU tensor.  The f32 entry points take raw pointers: a tensor of another dtype
+    (a bf16 style vector under torch.autocast, a float64 gradcheck input) would be read past its end on the device — it is
+    refused here, on the host, as a RuntimeError."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError(f'libfmgan_hip f32 entry point got a {t.dtype} tensor on {t.device}: float32 GPU tensors only '
+                           f'(cast before the call; under autocast the package\'s autograd Functions do)')
+    return t.data_ptr()
+
+
 class on_device:
     """Make the tensor's device current for the launch and hand out its current stream."""
 
@@ -196,7 +208,7 @@ def upfirdn2d_strided(in_ptr, device, major, in_h, in_w, plane_stride, row_strid
     out = torch.empty((major, out_h, out_w), dtype=torch.float32, device=device)
     with on_device(out) as stream:
         tok = _observer.begin('upfirdn2d', (major, in_h, in_w, out_h, out_w, 1, 1, 4))
-        check(lib().fmgan_upfirdn2d_strided(F32, in_ptr, ptr(k), ptr(out), major, in_h, in_w, 1, plane_stride,
+        check(lib().fmgan_upfirdn2d_strided(F32, in_ptr, fp(k), fp(out), major, in_h, in_w, 1, plane_stride,
                                             row_stride, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, force_path,
                                             stream), 'upfirdn2d_strided')
         _observer.end(tok)
@@ -221,12 +233,12 @@ def blur_noise_bias_act(in_ptr, device, batch, channels, in_h, in_w, plane_strid
     nz = noise.contiguous() if noise is not None else None
     if getattr(_observer, 'wants_paths', False):
         BLUR_PATHS[(batch * channels, in_h, in_w)] = lib().fmgan_blur_noise_bias_act_select(
-            in_ptr, ptr(out), ptr(nz), batch, channels, in_h, in_w, plane_stride, row_stride, kh, kw, pad0, pad1, pad0, pad1)
+            in_ptr, fp(out), fp(nz), batch, channels, in_h, in_w, plane_stride, row_stride, kh, kw, pad0, pad1, pad0, pad1)
     with on_device(out) as stream:
         tok = _observer.begin('upfirdn2d', (batch * channels, in_h, in_w, out_h, out_w, 1, 1, 4))
-        st = lib().fmgan_blur_noise_bias_act_path_f32(in_ptr, ptr(k), ptr(out), batch, channels, in_h, in_w,
-                                                      plane_stride, row_stride, kh, kw, pad0, pad1, pad0, pad1, ptr(nz),
-                                                      ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
+        st = lib().fmgan_blur_noise_bias_act_path_f32(in_ptr, fp(k), fp(out), batch, channels, in_h, in_w,
+                                                      plane_stride, row_stride, kh, kw, pad0, pad1, pad0, pad1, fp(nz),
+                                                      fp(noise_weight), fp(bias), 1 if nz is None else nz.shape[0],
                                                       float(alpha), float(scale), force_path, stream)
         _observer.end(tok)
     if st == -2:
@@ -277,7 +289,7 @@ def fused_bias_act_backward(grad_output, out, alpha, scale):
     partial = torch.empty((b, c, gx), dtype=torch.float32, device=g.device)
     with on_device(g) as stream:
         tok = _observer.begin('fused_bias_act', (g.numel(), 4))
-        st = lib().fmgan_fused_bias_act_bwd_f32(ptr(g), ptr(r), ptr(gi), ptr(partial), b * c, hw, float(alpha),
+        st = lib().fmgan_fused_bias_act_bwd_f32(fp(g), fp(r), fp(gi), fp(partial), b * c, hw, float(alpha),
                                                 float(scale), stream)
         _observer.end(tok)
     if st == -2:
@@ -296,7 +308,7 @@ def noise_bias_act(x, noise, noise_weight, bias, alpha, scale):
     out = torch.empty_like(x)
     with on_device(x) as stream:
         tok = _observer.begin('noise_bias_act', (x.numel(), 4))
-        check(lib().fmgan_noise_bias_act_f32(ptr(x), ptr(nz), ptr(noise_weight), ptr(bias), ptr(out), b, c, h * w, nb,
+        check(lib().fmgan_noise_bias_act_f32(fp(x), fp(nz), fp(noise_weight), fp(bias), fp(out), b, c, h * w, nb,
                                              float(alpha), float(scale), stream), 'noise_bias_act')
         _observer.end(tok)
     return out
@@ -313,7 +325,7 @@ def prelu_backward(x, grad, slope):
     gx = torch.empty_like(x)
     partial = torch.empty((blocks, c), dtype=torch.float32, device=x.device)
     with on_device(x) as stream:
-        st = lib().fmgan_prelu_backward_f32(ptr(x), ptr(grad), ptr(slope), ptr(gx), ptr(partial), rows, c, stream)
+        st = lib().fmgan_prelu_backward_f32(fp(x), fp(grad), fp(slope), fp(gx), fp(partial), rows, c, stream)
     if st == -2:
         return None
     check(st, 'prelu_backward')
@@ -328,10 +340,10 @@ def modconv_demod(weight, style, scale, eps=1e-8, wsq=None):
     demod = torch.empty((style.shape[0], cout), dtype=torch.float32, device=style.device)
     with on_device(style) as stream:
         if wsq is not None:
-            check(lib().fmgan_modconv_demod_wsq_f32(ptr(wsq), ptr(style), ptr(demod), style.shape[0], cout, cin,
+            check(lib().fmgan_modconv_demod_wsq_f32(fp(wsq), fp(style), fp(demod), style.shape[0], cout, cin,
                                                     float(scale), float(eps), stream), 'modconv_demod_wsq')
         else:
-            check(lib().fmgan_modconv_demod_f32(ptr(weight), ptr(style), ptr(demod), style.shape[0], cout, cin,
+            check(lib().fmgan_modconv_demod_f32(fp(weight), fp(style), fp(demod), style.shape[0], cout, cin,
                                                 kh * kw, float(scale), float(eps), stream), 'modconv_demod')
     return demod
 
@@ -341,7 +353,7 @@ def modconv_wsq(weight):
     cout, cin, kh, kw = weight.shape[-4:]
     wsq = torch.empty((cout, cin), dtype=torch.float32, device=weight.device)
     with on_device(weight) as stream:
-        check(lib().fmgan_modconv_wsq_f32(ptr(weight), ptr(wsq), cout, cin, kh * kw, stream), 'modconv_wsq')
+        check(lib().fmgan_modconv_wsq_f32(fp(weight), fp(wsq), cout, cin, kh * kw, stream), 'modconv_wsq')
     return wsq
 
 
@@ -353,7 +365,7 @@ def modconv_weight_prep(weight, scale, kind=0):
     shape = (cin, kh * kw, cout) if kind == 0 else (cout, kh * kw, cin)
     wt = torch.empty(shape, dtype=torch.float32, device=weight.device)
     with on_device(weight) as stream:
-        check(lib().fmgan_modconv_weight_prep_f32(ptr(weight), ptr(wt), cout, cin, kh * kw, float(scale), int(kind),
+        check(lib().fmgan_modconv_weight_prep_f32(fp(weight), fp(wt), cout, cin, kh * kw, float(scale), int(kind),
                                                   stream), 'modconv_weight_prep')
     return wt
 
@@ -408,7 +420,7 @@ def modconv_weight_to_bf16(wt):
     nbytes = lib().fmgan_modconv_weight_bf16_bytes(cin, cout, taps)
     wtb = torch.empty(nbytes // 2, dtype=torch.int16, device=wt.device)
     with on_device(wt) as stream:
-        check(lib().fmgan_modconv_weight_to_bf16(ptr(wt), ptr(wtb), cin, cout, taps, stream), 'modconv_weight_to_bf16')
+        check(lib().fmgan_modconv_weight_to_bf16(fp(wt), ptr(wtb), cin, cout, taps, stream), 'modconv_weight_to_bf16')
     return wtb
 
 
@@ -434,8 +446,8 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
         wtb = modconv_weight_to_bf16(wt)
         with on_device(x) as stream:
             tok = _observer.begin('modconv2d_bf16', (b, cin, cout, h, w, mode))
-            check(lib().fmgan_modconv2d_bf16(ptr(x), ptr(wtb), ptr(style), ptr(demod), out_ptr, b, cin, cout, h, w, mode,
-                                             ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
+            check(lib().fmgan_modconv2d_bf16(fp(x), ptr(wtb), fp(style), fp(demod), out_ptr, b, cin, cout, h, w, mode,
+                                             fp(nz), fp(noise_weight), fp(bias), 1 if nz is None else nz.shape[0],
                                              int(bool(fuse_act)), float(alpha), float(act_scale), ops, ors, stream),
                   'modconv2d_bf16')
             _observer.end(tok)
@@ -444,9 +456,9 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with on_device(x) as stream:
         tok = _observer.begin('modconv2d', (b, cin, cout, h, w, mode))
-        check(lib().fmgan_modconv2d_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), out_ptr, b, cin, cout, h, w, mode,
-                                        ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
-                                        int(bool(fuse_act)), float(alpha), float(act_scale), ops, ors, ptr(ws), ws_bytes,
+        check(lib().fmgan_modconv2d_f32(fp(x), fp(wt), fp(style), fp(demod), out_ptr, b, cin, cout, h, w, mode,
+                                        fp(nz), fp(noise_weight), fp(bias), 1 if nz is None else nz.shape[0],
+                                        int(bool(fuse_act)), float(alpha), float(act_scale), ops, ors, fp(ws), ws_bytes,
                                         stream), 'modconv2d')
         _observer.end(tok)
     return out
@@ -472,13 +484,13 @@ def modconv2d_rgb(x, wt, style, demod, noise, noise_weight, bias, alpha, act_sca
     sk = rgb_skip.contiguous() if rgb_skip is not None else None
     wmod = torch.empty((b, 3, cout), dtype=torch.float32, device=x.device)
     with on_device(x) as stream:
-        check(lib().fmgan_torgb_weight_mod_f32(ptr(rgb_weight), ptr(rgb_style), ptr(wmod), b, cout, rgb_c,
+        check(lib().fmgan_torgb_weight_mod_f32(fp(rgb_weight), fp(rgb_style), fp(wmod), b, cout, rgb_c,
                                                float(rgb_scale), stream), 'torgb_weight_mod')
         tok = _observer.begin('modconv2d', (b, cin, cout, h, w, 0))
-        check(lib().fmgan_modconv2d_rgb_f32(ptr(x), ptr(wt), ptr(style), ptr(demod), ptr(out), b, cin, cout, h, w,
-                                            ptr(nz), ptr(noise_weight), ptr(bias), 1 if nz is None else nz.shape[0],
-                                            1, float(alpha), float(act_scale), ptr(wmod), ptr(rgb_bias), ptr(sk),
-                                            ptr(rgb), rgb_c, stream), 'modconv2d_rgb')
+        check(lib().fmgan_modconv2d_rgb_f32(fp(x), fp(wt), fp(style), fp(demod), fp(out), b, cin, cout, h, w,
+                                            fp(nz), fp(noise_weight), fp(bias), 1 if nz is None else nz.shape[0],
+                                            1, float(alpha), float(act_scale), fp(wmod), fp(rgb_bias), fp(sk),
+                                            fp(rgb), rgb_c, stream), 'modconv2d_rgb')
         _observer.end(tok)
     return out, rgb
 
@@ -499,8 +511,8 @@ def modconv_wgrad(go, demod, x, style, scale, fast_only=False, mode=0):
     gw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     with on_device(x) as stream:
         tok = _observer.begin('modconv_wgrad', (b, cin, cout, h, w, int(mode)))
-        check(lib().fmgan_modconv_wgrad_mode_f32(ptr(go), ptr(demod), ptr(x), ptr(style), ptr(gw), b, cin, cout, h, w,
-                                                 int(mode), float(scale), ptr(ws), ws_bytes, stream), 'modconv_wgrad')
+        check(lib().fmgan_modconv_wgrad_mode_f32(fp(go), fp(demod), fp(x), fp(style), fp(gw), b, cin, cout, h, w,
+                                                 int(mode), float(scale), fp(ws), ws_bytes, stream), 'modconv_wgrad')
         _observer.end(tok)
     return gw
 
@@ -516,7 +528,7 @@ def torgb(x, weight, style, bias, skip, scale):
     out = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
     with on_device(x) as stream:
         tok = _observer.begin('torgb', (b, cin, cout, h * w))
-        check(lib().fmgan_torgb_f32(ptr(x), ptr(weight), ptr(style), ptr(bias), ptr(sk), ptr(out), b, cin, cout, h * w,
+        check(lib().fmgan_torgb_f32(fp(x), fp(weight), fp(style), fp(bias), fp(sk), fp(out), b, cin, cout, h * w,
                                     float(scale), stream), 'torgb')
         _observer.end(tok)
     return out
@@ -540,7 +552,7 @@ def torgb_backward(x, grad_out, weight, style, scale):
     wgt = weight.contiguous()
     with on_device(x) as stream:
         tok = _observer.begin('torgb_backward', (b, cin, cout, h * w))
-        st = lib().fmgan_torgb_backward_f32(ptr(x), ptr(go), ptr(wgt), ptr(style), ptr(gx), ptr(mpart), b, cin, cout, h * w,
+        st = lib().fmgan_torgb_backward_f32(fp(x), fp(go), fp(wgt), fp(style), fp(gx), fp(mpart), b, cin, cout, h * w,
                                             float(scale), stream)
         _observer.end(tok)
     if st == -2:

@@ -253,8 +253,19 @@ class ModulatedConv2dFunction(Function):
         return gx, gw, gs, None, None, None, None
 
 
+def _torgb_conv(x, weight, s, scale):
+    """ToRGB's 1x1 modulated conv without demodulation as a batched matmul: y[b] = (scale * W * s[b]) @ x[b].
+    Differentiable torch ops whose derivatives of every order are matmuls again.  (As a grouped F.conv2d its
+    double-backward — the path-length regulariser differentiates through ToRGB's backward — goes through PyTorch's generic
+    conv formula with the whole 1024^2 feature map as the FILTER: one 292 ms fall-back kernel per step, 60 % of the
+    path-length phase at 1024^2; profiles/r03_ppl_1024_kernels_before.md.)"""
+    b, cin, h, w = x.shape
+    wmod = (weight.reshape(1, -1, cin) * scale) * s[:, None, :]
+    return torch.bmm(wmod, x.reshape(b, cin, h * w)).view(b, -1, h, w)
+
+
 def _torgb_composite(x, weight, s, bias, skip, scale):
-    y = modconv_composite(x, weight, s, False, 0, scale)
+    y = _torgb_conv(x, weight, s, scale)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     if skip is not None:
@@ -290,7 +301,7 @@ class ToRGBFunction(Function):
             if not ctx.needs_input_grad[0]:
                 gx = None
         else:                                 # graph requested (path-length regulariser) / unserved shape: composite
-            gx, gw, gs = _regrad(lambda a, b, c: modconv_composite(a, b, c, False, 0, scale), (x, weight, s),
+            gx, gw, gs = _regrad(lambda a, b, c: _torgb_conv(a, b, c, scale), (x, weight, s),
                                  ctx.needs_input_grad[:3], grad_out)
         gb = grad_out.sum([0, 2, 3]).view(bias.shape) if ctx.needs_input_grad[3] else None
         gk = grad_out if (ctx.has_skip and ctx.needs_input_grad[4]) else None

@@ -370,6 +370,10 @@ class StyledConv(nn.Module):
 
     def fused_with_rgb(self, input, style, noise, to_rgb, rgb_latent, skip_up, keep_out):
         """StyledConv + ToRGB in one kernel (inference): returns (activation or None, rgb)."""
+        if torch.is_autocast_enabled():
+            with torch.autocast('cuda', enabled=False):
+                return self.fused_with_rgb(input.float(), style.float(), None if noise is None else noise.float(), to_rgb,
+                                           rgb_latent.float(), None if skip_up is None else skip_up.float(), keep_out)
         conv, act = self.conv, self.activate
         s = conv.styles(style)
         lv = live(conv)     # (wt, wsq) refreshed by the enclosing network's forward, if any
@@ -383,7 +387,13 @@ class StyledConv(nn.Module):
 
     def forward(self, input, style, return_style_scalars=False, noise=None):
         if (not torch.is_grad_enabled()) and modconv.hip_conv_ok(input, self.conv.weight) and not self.conv.downsample:
-            out, s = self._fused(input, style, noise)
+            if torch.is_autocast_enabled():
+                # the fused path hands raw fp32 pointers to the library: run it with autocast off on fp32 inputs (the style
+                # MLP would otherwise produce a bf16 vector; the training path gets this from its autograd Functions)
+                with torch.autocast('cuda', enabled=False):
+                    out, s = self._fused(input.float(), style.float(), None if noise is None else noise.float())
+            else:
+                out, s = self._fused(input, style, noise)
             if return_style_scalars:
                 return out, s.view(s.shape[0], 1, self.conv.in_channel, 1, 1)
             return out

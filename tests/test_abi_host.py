@@ -136,6 +136,21 @@ def test_product_has_no_cpu_path():
           use_external_input_tensor=True, external_input_tensor=torch.randn(1, 8, 4, 4))
 
 
+def test_raw_pointer_entry_points_refuse_other_dtypes():
+    """The f32 entry points take raw pointers; a bf16 / f64 / CPU tensor must be refused on the host (RuntimeError), never
+    handed to a kernel that would read past its end (round 3: a bf16 style vector under autocast faulted the GPU)."""
+    from op import _native
+    assert _native.fp(None) is None
+    for t in (torch.zeros(4, dtype=torch.bfloat16), torch.zeros(4, dtype=torch.float64), torch.zeros(4)):
+        with pytest.raises(RuntimeError):
+            _native.fp(t)
+    src = open(os.path.join(ROOT, '3d-fm-gan_amd', 'op', '_native.py')).read()
+    for fn in ('modconv2d', 'modconv_demod', 'torgb', 'torgb_backward', 'noise_bias_act', 'blur_noise_bias_act',
+               'modconv2d_rgb', 'modconv_wgrad', 'prelu_backward', 'fused_bias_act_backward'):
+        body = re.search(r'^def ' + fn + r'\(.*?(?=^def |\Z)', src, re.S | re.M).group(0)
+        assert ' ptr(' not in body.replace('ptr(wtb)', '') and 'fp(' in body, fn
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, '3d-fm-gan_amd')
     for dirpath, _, files in os.walk(pkg):

@@ -125,3 +125,34 @@ def test_bf16_generator_forward_within_stated_tolerance():
         g16, = torch.autograd.grad(G(None, **kw).abs().mean(), tsr_g)
     assert torch.isfinite(g16).all()
     assert float((g16 - g32).abs().max() / g32.abs().max()) < 0.1
+
+
+def test_inference_and_training_under_autocast_are_safe():
+    """torch.autocast(bfloat16) around the whole path (the bf16 leg): the style MLP then produces bf16 vectors and the
+    library convs bf16 activations.  The fused inference forward and every autograd Function must see fp32 (they hand raw
+    pointers to the library; round 3's first bf16 run faulted the GPU on a bf16 style vector): same image as without
+    autocast up to the bf16 rounding of the style MLP, finite gradients."""
+    import stylegan2
+    from op import _native
+    G = stylegan2.Generator(64, 512, 2)
+    G.load_state_dict(synth.state_dict('generator', G.state_dict(), seed=4))
+    G = G.to(dev()).eval()
+    lat = synth.tensor('ac/lat', (2, G.n_latent, 512)).to(dev())
+    tsr = synth.tensor('ac/tsr', (2, 512, 4, 4)).to(dev())
+    kw = dict(latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True, randomize_noise=False)
+    with torch.no_grad():
+        ref = G(None, external_input_tensor=tsr, **kw)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            a = G(None, external_input_tensor=tsr, **kw)
+            b = G(None, external_input_tensor=tsr.bfloat16(), **kw)       # what an autocast encoder hands over
+            with _native.modconv_precision('bf16'):
+                c = G(None, external_input_tensor=tsr, **kw)
+    for img in (a, b, c):
+        assert img.dtype == torch.float32 and torch.isfinite(img).all()
+        assert float((img - ref).abs().max() / ref.abs().max()) < 5e-2
+    G.requires_grad_(True)
+    t = tsr.clone().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16), _native.modconv_precision('bf16'):
+        img = G(None, external_input_tensor=t, **kw)
+        (img.float().abs().mean()).backward()
+    assert torch.isfinite(t.grad).all() and all(torch.isfinite(p.grad).all() for p in G.parameters() if p.grad is not None)
