@@ -9,6 +9,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The variant / ablation / clock switches exist only in the experiments build of the library (round 3: the product library
+# reads no environment variable): `make -C 3d-fm-gan_amd/csrc experiments` -> tools/exp/lib/libfmgan_hip_exp.so
+_EXP = os.path.join(ROOT, 'tools', 'exp', 'lib', 'libfmgan_hip_exp.so')
+if 'FMGAN_LIB' not in os.environ:
+    if not os.path.exists(_EXP):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, '3d-fm-gan_amd', 'csrc'), 'experiments'])
+    os.environ['FMGAN_LIB'] = _EXP
 VARIANTS = os.environ.get('FMGAN_BENCH_VARIANTS', 'ABC')
 LAYERS = [(4, 512, 512, 0), (4, 512, 512, 1), (8, 512, 512, 0), (8, 512, 512, 1), (16, 512, 512, 0), (16, 512, 512, 1),
           (32, 512, 512, 0), (32, 512, 512, 1), (64, 512, 512, 0), (64, 512, 256, 1), (128, 256, 256, 0), (128, 256, 128, 1),

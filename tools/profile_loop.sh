@@ -1,4 +1,6 @@
 #!/bin/bash
+# FMGAN_MC_DEBUG exists only in the experiments build: make -C 3d-fm-gan_amd/csrc experiments
+export FMGAN_LIB=${FMGAN_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/tools/exp/lib/libfmgan_hip_exp.so}
 # PMC breakdown of the MFMA loop (run ON the GPU box): where do the wave-cycles of modconv_mfma_f32 go, next to the
 # ideal "ds_read -> MFMA" loop of tools/exp/mfma_lds_probe.  usage: tools/profile_loop.sh <tag>
 set -e
