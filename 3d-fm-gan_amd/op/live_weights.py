@@ -37,6 +37,16 @@ class LiveWeights:
         self._n = 0
         self._buffers = []
 
+    def __deepcopy__(self, memo):
+        """A copy of the network (g_ema = deepcopy(G)) starts WITHOUT table and buffers: the copied table would still
+        hold the raw pointers of the original's parameters and buffers, and the pointer key alone does not protect a
+        copy whose parameters later land on the original's old addresses."""
+        import copy
+        new = LiveWeights.__new__(LiveWeights)
+        memo[id(self)] = new
+        new.__init__(copy.deepcopy(self.root, memo))
+        return new
+
     def _sources(self):
         from stylegan2 import EqualLinear, ModulatedConv2d
         lin, conv = [], []

@@ -11,8 +11,9 @@ between launches" in-step rate of the headline blur (0.58 or 0.64 of the HBM roo
 
 User code can neither read nor choose physical placement.  It can MEASURE: for the few layers whose intermediate is large
 enough to matter, the no_grad forward keeps a persistent (intermediate, output) pair, chosen once — candidates are
-allocated one at a time (with an 8 GiB ballast in between: the class flips every ~8 GiB of the allocation frontier,
-profiles/r03_block_class_scan.md — which looks like one physical address bit of that weight in the channel / bank hash)
+allocated one at a time (with a 4 GiB ballast from the driver in between: the class changes every 4-16 GiB of the
+allocation frontier, profiles/r03_block_class_scan.md — the weight of high-order physical address bits in the channel /
+bank hash)
 and timed on the layer's real producer + blur launches until both classes have been seen (or a cap is reached); the
 fastest pair is kept, candidates and ballast go back to torch's caching allocator.  The buffers are private to one module, one shape and one
 stream; they never leave the synthesis network (its only output is the ToRGB image), so reuse across forwards is ordered
@@ -25,9 +26,9 @@ import torch
 
 ENABLED = os.environ.get('FMGAN_PLACEMENT', '1') != '0'
 LOG = os.environ.get('FMGAN_PLACEMENT_LOG', '0') != '0'
-MIN_BYTES = 256 << 20        # intermediates smaller than this fit the 256 MiB Infinity Cache: no placement effect measured
-MAX_CANDIDATES = 4           # blocks tried per role before settling for the best pair seen
-BALLAST_BYTES = 8 << 30      # allocation-frontier distance after which the placement class has usually flipped
+MIN_BYTES = 384 << 20        # smaller pairs showed no placement contrast in any selection log (profiles/r03_placement_selection.md)
+MAX_CANDIDATES = 10          # blocks tried per role before settling for the best pair seen
+BALLAST_BYTES = 4 << 30      # frontier distance put between two candidates (runs of one class are 4-16 GiB long)
 CONTRAST = 1.03              # both classes seen once the fastest pair beats the slowest by 3 % (the classes differ by 6-7 %)
 
 _STORE = weakref.WeakKeyDictionary()     # module -> {key: workspace}; never deep-copied, never in a state_dict
@@ -52,6 +53,39 @@ class scope:
 
 def active():
     return ENABLED and _depth > 0
+
+
+class _Ballast:
+    """Device memory taken straight from the driver (hipMalloc through ctypes) to move the allocation frontier between
+    two candidates; never enters torch's caching allocator and is returned to the driver when the selection ends."""
+
+    def __init__(self, device):
+        self.device, self.ptrs, self.hip = device, [], None
+        try:
+            import ctypes
+            self.ct = ctypes
+            self.hip = ctypes.CDLL('libamdhip64.so')
+            self.hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            self.hip.hipFree.argtypes = [ctypes.c_void_p]
+        except OSError:
+            self.hip = None
+
+    def grow(self):
+        if self.hip is None:
+            return
+        free, _ = torch.cuda.mem_get_info(self.device)
+        if free < 4 * BALLAST_BYTES:           # never push a loaded device towards its limit for a 7 % effect
+            return
+        p = self.ct.c_void_p()
+        with torch.cuda.device(self.device):
+            if self.hip.hipMalloc(self.ct.byref(p), BALLAST_BYTES) == 0 and p.value:
+                self.ptrs.append(p)
+
+    def free(self):
+        with torch.cuda.device(self.device):
+            for p in self.ptrs:
+                self.hip.hipFree(p)
+        self.ptrs = []
 
 
 class Workspace:
@@ -88,31 +122,36 @@ def workspace(owner, key, buf_shape, out_shape, device, produce, consume):
     if torch.cuda.is_current_stream_capturing():
         return None          # selection needs timed launches: not inside a HIP-graph capture (warm up eagerly first)
     # Candidates for the output are timed against intermediate candidate 0.  Blocks allocated back to back share a class
-    # for ~8 GiB of the allocation frontier (profiles/r03_block_class_scan.md), so from the second candidate on a ballast
-    # of that size is allocated first: the next candidate then usually lies in the other class.  (When torch's caching
-    # allocator serves a candidate from a cached block instead, its class is arbitrary — the measurement decides.)  The
-    # relation is symmetric and two-class: if no output candidate shows contrast, intermediates are tried the same way.
+    # for 4-16 GiB of the allocation frontier (profiles/r03_block_class_scan.md: runs of 4, 8, 12 blocks of 1.03 GiB on
+    # different boxes), so from the second candidate on a ballast is allocated first — straight from the driver, not
+    # through torch's caching allocator, and freed when the selection ends — and the next candidate lies further along
+    # the frontier.  (When the caching allocator serves a candidate from a cached block instead, its class is arbitrary:
+    # the measurement decides.)  The relation is symmetric and two-class: if no output candidate shows contrast against
+    # intermediate 0, intermediates are tried against the best output the same way.
     bufs = [torch.empty(buf_shape, dtype=torch.float32, device=device)]
-    outs, rates, ballast = [], [], []
-    for c in range(MAX_CANDIDATES):
-        if c >= 1:
-            ballast.append(torch.empty(BALLAST_BYTES, dtype=torch.uint8, device=device))
-        outs.append(torch.empty(out_shape, dtype=torch.float32, device=device))
-        rates.append(_time(produce, consume, bufs[0], outs[-1]))      # (times: smaller is faster)
-        if len(rates) > 1 and max(rates) >= min(rates) * CONTRAST:
-            break          # both classes seen
-    j = min(range(len(rates)), key=rates.__getitem__)
-    best = (0, j, rates[j])
-    if max(rates) < min(rates) * CONTRAST:
-        for _ in range(MAX_CANDIDATES - 1):
-            ballast.append(torch.empty(BALLAST_BYTES, dtype=torch.uint8, device=device))
-            bufs.append(torch.empty(buf_shape, dtype=torch.float32, device=device))
-            t = _time(produce, consume, bufs[-1], outs[j])
-            if t < best[2]:
-                best = (len(bufs) - 1, j, t)
-            if t * CONTRAST <= rates[j]:
-                break
-    del ballast
+    outs, rates = [], []
+    ballast = _Ballast(device)
+    try:
+        for c in range(MAX_CANDIDATES):
+            if c >= 1:
+                ballast.grow()
+            outs.append(torch.empty(out_shape, dtype=torch.float32, device=device))
+            rates.append(_time(produce, consume, bufs[0], outs[-1]))      # (times: smaller is faster)
+            if len(rates) > 1 and max(rates) >= min(rates) * CONTRAST:
+                break          # both classes seen
+        j = min(range(len(rates)), key=rates.__getitem__)
+        best = (0, j, rates[j])
+        if max(rates) < min(rates) * CONTRAST:
+            for _ in range(MAX_CANDIDATES - 1):
+                ballast.grow()
+                bufs.append(torch.empty(buf_shape, dtype=torch.float32, device=device))
+                t = _time(produce, consume, bufs[-1], outs[j])
+                if t < best[2]:
+                    best = (len(bufs) - 1, j, t)
+                if t * CONTRAST <= rates[j]:
+                    break
+    finally:
+        ballast.free()
     ws = Workspace(bufs[best[0]], outs[best[1]], best[2], len(bufs) + len(outs))
     if LOG:
         import sys

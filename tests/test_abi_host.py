@@ -328,3 +328,20 @@ def test_conv_grad_family_matches_conv2d_autograd_at_every_order(geom):
         outs.append((y.detach(), gx.detach(), gw.detach(), g3))
     for a, c in zip(*outs):
         torch.testing.assert_close(a, c, rtol=1e-10, atol=1e-10)
+
+
+def test_live_weights_deepcopy_starts_without_table():
+    """copy.deepcopy(G) (how Trainer builds g_ema): the copy's LiveWeights must not inherit the original's device table or
+    pointer key (raw pointers of the ORIGINAL's parameters and buffers); it is bound to the copied network."""
+    import copy
+    import stylegan2
+    from op.live_weights import LiveWeights
+    G = stylegan2.Generator(8, 16, 1, generator_net_shape=[8, 8, 8])
+    lw = LiveWeights(G)
+    lw._key, lw._table, lw._n, lw._blocks, lw._buffers = ('stale',), torch.zeros(4), 3, 7, [torch.zeros(1)]
+    G._live_weights = lw
+    G2 = copy.deepcopy(G)
+    lw2 = G2._live_weights
+    assert lw2 is not lw and lw2.root is G2
+    assert lw2._key is None and lw2._table is None and lw2._buffers == [] and not lw2.active
+    assert lw._key == ('stale',)
