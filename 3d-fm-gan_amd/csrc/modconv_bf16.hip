@@ -22,9 +22,11 @@
 //   * weight staging: the per-chunk image [tap][h][o][8] is contiguous per (tap, h) in the prepared array and goes
 //     HBM -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA, no staging registers) into the weight image the current
 //     chunk is not reading;
-//   * MODE 1 (transposed conv): position (m, n) owns the output quad (2m+py, 2n+px); the main launch covers m < h,
-//     n < w, i.e. output rows < 2h and columns < 2w; the last output row and column (1/(2h+1) of the outputs, <= 2
-//     taps each) come from a small direct kernel with the same rounded operands.
+//   * MODE 1 (transposed conv): position (m, n) owns the output quad (2m+py, 2n+px) over the (h+1) x (w+1) quad grid; the
+//     positions m = h / n = w own only the last output row / column (their other outputs are masked in the store).  A
+//     separate direct kernel for that row and column was the first form: one thread per element with a serial loop over
+//     Cin made the 32^2..64^2 layers SLOWER than the fp32 kernel (1083 vs 504 us at 32^2); the extra tile column costs
+//     the MFMA launch far less.
 // Shapes it serves: cin % 16 == 0, cout % 32 == 0, position grid at least 32 wide; everything else returns
 // FMGAN_EUNSUPPORTED and the caller keeps the fp32 kernel (the 4^2..16^2 layers: < 3 % of the FLOPs at B=8).
 #include "common.h"
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_bf16(const BFParams p) {
         }
       } else {
         float* dpos = dst_b + (long long)(vg ? 2 * py_ : 0) * p.out_row_stride + (vg ? 2 * px_ : 0);
+        const bool pair = 2 * px_ + 1 < p.ow;          // position n = w owns the last output column only
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
@@ -302,46 +305,19 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_bf16(const BFParams p) {
           float* dst = dpos + (long long)o * p.out_plane_stride;
 #pragma unroll
           for (int py = 0; py < 2; ++py) {
-            f32x2_u t;
-            t.x = acc[m][g][py * 2][r] * dm_m[r];
-            t.y = acc[m][g][py * 2 + 1][r] * dm_m[r];
-            *reinterpret_cast<f32x2_u*>(dst + (long long)py * p.out_row_stride) = t;
+            if (2 * py_ + py >= p.oh) continue;          // position m = h owns the last output row only
+            const float v0 = acc[m][g][py * 2][r] * dm_m[r], v1 = acc[m][g][py * 2 + 1][r] * dm_m[r];
+            if (pair) {
+              f32x2_u t;
+              t.x = v0; t.y = v1;
+              *reinterpret_cast<f32x2_u*>(dst + (long long)py * p.out_row_stride) = t;
+            } else {
+              dst[(long long)py * p.out_row_stride] = v0;
+            }
           }
         }
       }
     }
-  }
-}
-
-// MODE 1, last output row (Y = 2h) and last output column (X = 2w): every product there has ky = 2 resp. kx = 2.
-// One thread per output element, fp32 accumulation of the same bf16-rounded operands.
-__global__ __launch_bounds__(256) void modconv_bf16_edge(const BFParams p) {
-  const int edge = p.ow + p.oh - 1;                         // last row (ow elements) + last column without the corner
-  const long long total = (long long)p.batch * p.cout * edge;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int e = (int)(idx % edge);
-    const long long r = idx / edge;
-    const int o = (int)(r % p.cout), b = (int)(r / p.cout);
-    const int Y = e < p.ow ? p.oh - 1 : e - p.ow, X = e < p.ow ? e : p.ow - 1;
-    float acc = 0.f;
-    for (int ky = Y & 1; ky < 3; ky += 2) {
-      const int iy = (Y - ky) >> 1;
-      if (Y - ky < 0 || iy >= p.h) continue;
-      for (int kx = X & 1; kx < 3; kx += 2) {
-        const int ix = (X - kx) >> 1;
-        if (X - kx < 0 || ix >= p.w) continue;
-        const int tap = ky * 3 + kx;
-        for (int i = 0; i < p.cin; ++i) {
-          const float xs = p.in[(((long long)b * p.cin + i) * p.h + iy) * p.w + ix] * p.style[(long long)b * p.cin + i];
-          const float xb = bf16_to_f32((unsigned short)(pack_bf16(xs, 0.f) & 0xffffu));
-          const unsigned short wq = p.wt[((((long long)(i >> 4) * 9 + tap) * 2 + ((i >> 3) & 1)) * p.mp + o) * 8 + (i & 7)];
-          acc = fmaf(bf16_to_f32(wq), xb, acc);
-        }
-      }
-    }
-    if (p.demod) acc *= p.demod[(long long)b * p.cout + o];
-    p.out[((long long)b * p.cout + o) * p.out_plane_stride + (long long)Y * p.out_row_stride + X] = acc;
   }
 }
 
@@ -413,7 +389,7 @@ extern "C" int fmgan_modconv2d_bf16(const float* in, const void* wt_bf16, const 
   BFParams p{};
   p.in = in; p.wt = (const unsigned short*)wt_bf16; p.style = style; p.demod = demod; p.out = out;
   p.batch = batch; p.cin = cin; p.cout = cout; p.h = h; p.w = w;
-  if (mode == 1) { p.oh = 2 * h + 1; p.ow = 2 * w + 1; p.gh = h; p.gw = w; }
+  if (mode == 1) { p.oh = 2 * h + 1; p.ow = 2 * w + 1; p.gh = h + 1; p.gw = w + 1; }   // quads (m <= h, n <= w)
   else if (mode == 2) { p.oh = (h - 3) / 2 + 1; p.ow = (w - 3) / 2 + 1; p.gh = p.oh; p.gw = p.ow; }
   else { p.oh = h; p.ow = w; p.gh = h; p.gw = w; }
   if (out_row_stride == 0) out_row_stride = p.ow;
@@ -436,13 +412,6 @@ extern "C" int fmgan_modconv2d_bf16(const float* in, const void* wt_bf16, const 
   } else {
     if (cout >= 64) st = launch_bf16<1, 2, 1>(p, s);
     else st = launch_bf16<1, 1, 2>(p, s);
-    if (st != FMGAN_OK) return st;
-    const long long total = (long long)batch * cout * (p.ow + p.oh - 1);
-    long long blocks = (total + 255) / 256;
-    const long long cap = (long long)FMGAN_NUM_CU * 32;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(modconv_bf16_edge, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    st = fmgan_check_launch();
   }
   return st;
 }

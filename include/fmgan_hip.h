@@ -288,8 +288,8 @@ int fmgan_modconv2d_f32(const float *in, const float *wt, const float *style,
  *       image [cin/16][tap][2][cout padded to 32][8].
  *   fmgan_modconv2d_bf16_supported: 1 when the shape is served (cin % 16 == 0, cout % 32 == 0, position grid >= 32 wide
  *       and >= 4 high, 32-bit buffer ranges); otherwise fmgan_modconv2d_bf16 returns FMGAN_EUNSUPPORTED and the caller
- *       keeps the fp32 kernel.  mode 1 writes output rows < 2h / columns < 2w from the MFMA launch and the last row and
- *       column from a direct kernel on the same rounded operands.
+ *       keeps the fp32 kernel.  mode 1 runs over the (h+1) x (w+1) quad grid; the quads m = h / n = w own only the last
+ *       output row / column.
  */
 long long fmgan_modconv_weight_bf16_bytes(int cin, int cout, int ktaps);
 int fmgan_modconv_weight_to_bf16(const float *wt, void *wt_bf16, int cin, int cout, int ktaps, void *stream);
