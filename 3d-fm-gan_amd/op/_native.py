@@ -67,6 +67,10 @@ def lib():
     _sig(L.fmgan_modconv_weight_to_bf16, [vp, vp, i, i, i, vp])
     _sig(L.fmgan_modconv2d_bf16_supported, [i] * 6)
     _sig(L.fmgan_modconv2d_bf16, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp])
+    _sig(L.fmgan_modconv_weight_bf16x3_bytes, [i] * 3, ll)
+    _sig(L.fmgan_modconv_weight_to_bf16x3, [vp, vp, i, i, i, vp])
+    _sig(L.fmgan_modconv2d_bf16x3_supported, [i] * 6)
+    _sig(L.fmgan_modconv2d_bf16x3, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp])
     _sig(L.fmgan_modconv2d_rgb_fusable, [i] * 5)
     _sig(L.fmgan_torgb_weight_mod_f32, [vp] * 3 + [i] * 3 + [f, vp])
     _sig(L.fmgan_modconv2d_rgb_f32, [vp] * 5 + [i] * 5 + [vp] * 3 + [i, i, f, f] + [vp] * 4 + [i, vp])
@@ -389,8 +393,9 @@ def aligned_rows_buffer(b, c, oh, ow, pad0, device):
     return buf, buf.data_ptr() + 4 * off, oh * rs, rs
 
 
-# Contraction precision of modconv2d: 'f32' (default, the parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulation;
-# BASELINE config 5's reduced-precision leg).  Set through the context manager only.
+# Contraction of modconv2d: 'f32' (default, the parity path: v_mfma_f32_32x32x2_f32), 'bf16' (bf16 MFMA operands, fp32
+# accumulation; BASELINE config 5's reduced-precision leg) or 'bf16x3' (fp32 operands split into three bf16 pieces, six
+# bf16 MFMAs per product: fp32 accuracy at 2.7x the fp32 matrix rate; forward only, labelled).  Context manager only.
 _mc_precision = 'f32'
 
 
@@ -399,8 +404,8 @@ class modconv_precision:
     modulated conv) whose shape the bf16 kernel serves runs on v_mfma_f32_32x32x16_bf16; the rest stay fp32."""
 
     def __init__(self, precision):
-        if precision not in ('f32', 'bf16'):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if precision not in ('f32', 'bf16', 'bf16x3'):
+            raise ValueError("precision must be 'f32', 'bf16' or 'bf16x3'")
         self.precision = precision
 
     def __enter__(self):
@@ -424,6 +429,20 @@ def modconv_weight_to_bf16(wt):
     return wtb
 
 
+def modconv_weight_to_bf16x3(wt):
+    """fp32 MFMA layout wt [cin, taps, cout] -> its three bf16 operand images (hi, mid, lo) in one opaque tensor."""
+    cin, taps, cout = wt.shape
+    nbytes = lib().fmgan_modconv_weight_bf16x3_bytes(cin, cout, taps)
+    wts = torch.empty(nbytes // 2, dtype=torch.int16, device=wt.device)
+    with on_device(wt) as stream:
+        check(lib().fmgan_modconv_weight_to_bf16x3(fp(wt), ptr(wts), cin, cout, taps, stream), 'modconv_weight_to_bf16x3')
+    return wts
+
+
+def current_modconv_precision():
+    return _mc_precision
+
+
 def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=None, fuse_act=False, alpha=0.2,
               act_scale=2 ** 0.5, strided_out=None, precision=None):
     """x [B,cin,H,W] f32, wt from modconv_weight_prep (3x3), style [B,cin], demod [B,cout] or None.
@@ -442,7 +461,18 @@ def modconv2d(x, wt, style, demod, mode, noise=None, noise_weight=None, bias=Non
         out = None
         out_ptr, ops, ors = strided_out
     nz = noise.contiguous() if noise is not None else None
-    if (precision or _mc_precision) == 'bf16' and lib().fmgan_modconv2d_bf16_supported(b, cin, cout, h, w, mode):
+    prec = precision or _mc_precision
+    if prec == 'bf16x3' and lib().fmgan_modconv2d_bf16x3_supported(b, cin, cout, h, w, mode):
+        wts = modconv_weight_to_bf16x3(wt)
+        with on_device(x) as stream:
+            tok = _observer.begin('modconv2d_bf16x3', (b, cin, cout, h, w, mode))
+            check(lib().fmgan_modconv2d_bf16x3(fp(x), ptr(wts), fp(style), fp(demod), out_ptr, b, cin, cout, h, w, mode,
+                                               fp(nz), fp(noise_weight), fp(bias), 1 if nz is None else nz.shape[0],
+                                               int(bool(fuse_act)), float(alpha), float(act_scale), ops, ors, stream),
+                  'modconv2d_bf16x3')
+            _observer.end(tok)
+        return out
+    if prec == 'bf16' and lib().fmgan_modconv2d_bf16_supported(b, cin, cout, h, w, mode):
         wtb = modconv_weight_to_bf16(wt)
         with on_device(x) as stream:
             tok = _observer.begin('modconv2d_bf16', (b, cin, cout, h, w, mode))

@@ -365,6 +365,8 @@ class StyledConv(nn.Module):
         conv = self.conv
         if conv.upsample or conv.downsample or torch.is_grad_enabled() or not modconv.hip_conv_ok(x, conv.weight):
             return False
+        if _native.current_modconv_precision() != 'f32':     # the RGB epilogue exists on the fp32 MFMA kernel only
+            return False
         b, _, h, w = x_shape
         return _native.modconv2d_rgb_fusable(b, conv.in_channel, conv.out_channel, h, w)
 

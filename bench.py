@@ -563,6 +563,20 @@ def main():
         dt = timed(lambda: graphed(*inputs), args.steps, 2, world)   # the same forward, replayed as one HIP graph
     pairs_per_s = world * batch * args.steps / dt
     log(f'{args.workload}: {pairs_per_s:.1f} pairs/s')
+    # LABELLED variant, never `value`: the same forward with the modulated convs' fp32 contraction emulated on the bf16
+    # matrix pipe (operands split into three bf16 pieces, six MFMAs per product, fp32 accumulation: fp32 accuracy, held to
+    # the fp32 path's gates by tests/test_hip_modconv_bf16.py).  Timed with the same barriers right after the headline.
+    x3 = None
+    if args.workload == 'pairs1024' and not args.graph:
+        def step_x3():
+            with _native.modconv_precision('bf16x3'):
+                return step()
+        dt3 = timed(step_x3, args.steps, 3, world)
+        x3 = {'pairs_per_s': world * batch * args.steps / dt3, 'ms_per_step': 1e3 * dt3 / args.steps,
+              'what': 'pairs1024 with the 3x3 modulated convs on v_mfma_f32_32x32x16_bf16 via exact 3-way bf16 operand '
+                      'splitting (6 MFMAs per product, fp32 accumulate; csrc/modconv_bf16.hip) - fp32-accurate, labelled, '
+                      'not the headline'}
+        log(f"pairs1024 with split-operand contraction: {x3['pairs_per_s']:.1f} pairs/s")
 
     out = {
         'metric': '(photo,render) pairs/sec', 'value': pairs_per_s, 'unit': 'pairs/s', 'n_gpus': world,
@@ -573,6 +587,8 @@ def main():
                    'launch': 'eager' if graphed is None else 'hip-graph replay of the whole forward', **dist_info(world)},
         'eager': {'value': world * batch * args.steps / dt_eager, 'ms_per_step': 1e3 * dt_eager / args.steps},
     }
+    if x3 is not None:
+        out['pairs1024_bf16x3'] = x3
 
     # roofline of the dominant HBM kernel (upfirdn2d headline call), algorithmic bytes = 4*(in + out)
     summ = timer.summary()

@@ -301,6 +301,23 @@ int fmgan_modconv2d_bf16(const float *in, const void *wt_bf16, const float *styl
                          long long out_plane_stride, int out_row_stride, void *stream);
 
 /*
+ * fp32 contraction on the bf16 matrix pipe by operand splitting ("bf16x3"; forward modes 0 and 1; a LABELLED path, not
+ * the parity path): each fp32 operand is split exactly into three bf16 pieces (hi + mid + lo) and the product is
+ * accumulated in fp32 from the six largest piece products (ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh; the dropped
+ * terms are O(2^-24) of the product, one fp32 rounding), on v_mfma_f32_32x32x16_bf16 — 16/6 = 2.7x the matrix-pipe rate of
+ * v_mfma_f32_32x32x2_f32 at fp32 accuracy.  Same arguments and epilogue as fmgan_modconv2d_f32; wt_split from
+ * fmgan_modconv_weight_to_bf16x3 (the fp32 MFMA layout split into three bf16 operand images).
+ */
+long long fmgan_modconv_weight_bf16x3_bytes(int cin, int cout, int ktaps);
+int fmgan_modconv_weight_to_bf16x3(const float *wt, void *wt_split, int cin, int cout, int ktaps, void *stream);
+int fmgan_modconv2d_bf16x3_supported(int batch, int cin, int cout, int h, int w, int mode);
+int fmgan_modconv2d_bf16x3(const float *in, const void *wt_split, const float *style, const float *demod, float *out,
+                           int batch, int cin, int cout, int h, int w, int mode,
+                           const float *noise, const float *noise_weight, const float *bias,
+                           int noise_batch, int fuse_act, float alpha, float act_scale,
+                           long long out_plane_stride, int out_row_stride, void *stream);
+
+/*
  * Plain (mode 0) modulated conv with the FOLLOWING ToRGB layer folded into its epilogue.  In the reference these are
  * two modules and three HBM passes over the activation (StyledConv conv2 -> ToRGB, stylegan2.py:646-651 calling
  * :360-376 and :393-404).  When one block holds every output channel of its pixels (cout <= the tile's channel

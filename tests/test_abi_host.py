@@ -148,7 +148,7 @@ def test_raw_pointer_entry_points_refuse_other_dtypes():
     for fn in ('modconv2d', 'modconv_demod', 'torgb', 'torgb_backward', 'noise_bias_act', 'blur_noise_bias_act',
                'modconv2d_rgb', 'modconv_wgrad', 'prelu_backward', 'fused_bias_act_backward'):
         body = re.search(r'^def ' + fn + r'\(.*?(?=^def |\Z)', src, re.S | re.M).group(0)
-        assert ' ptr(' not in body.replace('ptr(wtb)', '') and 'fp(' in body, fn
+        assert ' ptr(' not in body.replace('ptr(wtb)', '').replace('ptr(wts)', '') and 'fp(' in body, fn
 
 
 def test_product_never_imports_oracle():

@@ -156,3 +156,65 @@ def test_inference_and_training_under_autocast_are_safe():
         img = G(None, external_input_tensor=t, **kw)
         (img.float().abs().mean()).backward()
     assert torch.isfinite(t.grad).all() and all(torch.isfinite(p.grad).all() for p in G.parameters() if p.grad is not None)
+
+
+# ------------------------------------------------------------------------------------------------ bf16x3: fp32 by splitting
+X3_CASES = [(2, 32, 32, 64, 64, 0), (1, 16, 32, 40, 33, 0), (2, 64, 64, 32, 32, 0), (1, 48, 96, 37, 70, 0), (3, 128, 160, 36, 32, 0),
+            (1, 512, 512, 64, 64, 0), (2, 32, 32, 64, 64, 1), (1, 16, 32, 9, 33, 1), (2, 64, 64, 32, 32, 1), (1, 48, 96, 21, 45, 1),
+            (1, 512, 256, 64, 64, 1)]
+
+
+@pytest.mark.parametrize('cfg', X3_CASES)
+@pytest.mark.parametrize('demod', [True, False])
+def test_bf16x3_kernel_has_fp32_accuracy(cfg, demod):
+    """fmgan_modconv2d_bf16x3 (fp32 operands split into three bf16 pieces, six bf16 MFMAs per product) against a float64
+    convolution of the UNROUNDED operands: it must be as accurate as the fp32 MFMA kernel — its error vs float64 at most
+    2x the fp32 kernel's + 2e-6 of max|out| — and within the fp32 kernel's oracle tolerance (2e-5) of it."""
+    from op import _native
+    b, cin, cout, h, w, mode = cfg
+    x, wgt, s, scale = _inputs(cfg)
+    assert _native.lib().fmgan_modconv2d_bf16x3_supported(b, cin, cout, h, w, mode) == 1
+    xd, wd, sd = x.to(dev()), wgt.to(dev()), s.to(dev())
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale) if demod else None
+    y3 = _native.modconv2d(xd, wt, sd, dm, mode, precision='bf16x3')
+    y32 = _native.modconv2d(xd, wt, sd, dm, mode, precision='f32')
+    u = (x.float() * s.float()[:, :, None, None]).double()
+    wq = (wgt.float() * torch.tensor(scale, dtype=torch.float32)).double()
+    ref = torch.nn.functional.conv2d(u, wq, padding=1) if mode == 0 else torch.nn.functional.conv_transpose2d(u, wq.transpose(0, 1), stride=2)
+    if dm is not None:
+        ref = ref * dm.cpu().double()[:, :, None, None]
+    mx = float(ref.abs().max())
+    e3 = float((y3.cpu().double() - ref).abs().max()) / mx
+    e32 = float((y32.cpu().double() - ref).abs().max()) / mx
+    assert e3 <= 2 * e32 + 2e-6, (e3, e32)
+    assert float((y3 - y32).abs().max()) / mx <= 2e-5
+    assert torch.equal(_native.modconv2d(xd, wt, sd, dm, mode, precision='bf16x3'), y3)      # bit-reproducible
+
+
+def test_bf16x3_generator_meets_the_fp32_path_gates(golden):
+    """Generator(256) and Generator(1024) full width with every served layer on the split-operand contraction: the fp32
+    path's own gates — 1e-4 vs the reference's fp32 image (BASELINE §4) and 'no farther from the float64 image than
+    4 x the reference's fp32 error + 2e-6' (tests/test_hip_models.py)."""
+    import cases
+    import stylegan2
+    from op import _native
+    g32, g64 = golden('generator'), golden('fp64')
+    for c in cases.GENERATOR_CASES:
+        if c['name'] not in ('g256_full', 'g1024_full'):
+            continue
+        G = stylegan2.Generator(c['size'], 512, c['n_mlp'])
+        G.load_state_dict(synth.state_dict('generator', G.state_dict(), seed=4))
+        G = G.to(dev()).eval()
+        lat = synth.tensor(c['name'] + '/latent', (c['b'], G.n_latent, 512)).to(dev())
+        tsr = synth.tensor(c['name'] + '/tsr', (c['b'], 512, 4, 4)).to(dev())
+        with torch.no_grad(), _native.modconv_precision('bf16x3'):
+            img = G(None, latent_styles=[lat], input_is_latent=True, use_external_input_tensor=True,
+                    external_input_tensor=tsr, randomize_noise=False)
+        a = img.cpu().numpy()[..., ::c['stride'], ::c['stride']]
+        r32, r64 = g32[c['name'] + '/sub'], g64[c['name'] + '/sub']
+        mx = float(np.abs(r64).max())
+        np.testing.assert_allclose(a, r32, atol=1e-4 * mx, rtol=1e-4)
+        e_hip, e_ref = np.abs(a - r64).max() / mx, np.abs(r32 - r64).max() / mx
+        assert e_hip <= 4 * e_ref + 2e-6, (c['name'], e_hip, e_ref)
+        del G

@@ -30,8 +30,8 @@ def t(fn, n=5):
     return a.elapsed_time(b) / n * 1e3
 
 
-print(f'| layer (B={B}) | mode | fp32 us | TFLOP/s | bf16 us | TFLOP/s | speed-up | max |bf16-fp32| / max |')
-print('|---|---|---|---|---|---|---|---|')
+print(f'| layer (B={B}) | mode | fp32 us | TFLOP/s | bf16 us | TFLOP/s | speed-up | max |bf16-fp32| / max | bf16x3 us | eff. TFLOP/s | vs fp32 | max |bf16x3-fp32| / max |')
+print('|---|---|---|---|---|---|---|---|---|---|---|---|')
 for r, cin, cout, mode in LAYERS:
     x = torch.randn(B, cin, r, r, device=d)
     w = torch.randn(cout, cin, 3, 3, device=d)
@@ -47,5 +47,11 @@ for r, cin, cout, mode in LAYERS:
     y32 = _native.modconv2d(x, wt, s, dm, mode, precision='f32')
     y16 = _native.modconv2d(x, wt, s, dm, mode, precision='bf16')
     err = float((y16 - y32).abs().max() / y32.abs().max())
-    print(f'| {r}^2 {cin}->{cout} | {mode} | {t32:.0f} | {fl / t32 / 1e6:.1f} | {t16:.0f} | {fl / t16 / 1e6:.1f} | {t32 / t16:.2f} | {err:.1e} |')
+    x3 = ' - | - | - | - |'
+    if _native.lib().fmgan_modconv2d_bf16x3_supported(B, cin, cout, r, r, mode):
+        t3 = t(lambda: _native.modconv2d(x, wt, s, dm, mode, precision='bf16x3'))
+        y3 = _native.modconv2d(x, wt, s, dm, mode, precision='bf16x3')
+        e3 = float((y3 - y32).abs().max() / y32.abs().max())
+        x3 = f' {t3:.0f} | {fl / t3 / 1e6:.1f} | {t32 / t3:.2f} | {e3:.1e} |'
+    print(f'| {r}^2 {cin}->{cout} | {mode} | {t32:.0f} | {fl / t32 / 1e6:.1f} | {t16:.0f} | {fl / t16 / 1e6:.1f} | {t32 / t16:.2f} | {err:.1e} |' + x3)
     del x, y32, y16
