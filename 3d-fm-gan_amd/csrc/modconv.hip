@@ -30,6 +30,8 @@ namespace {
 // rsrc base + voff (per lane, range-checked against the resource: out of range -> zeros) + soff (wave-uniform).
 // (Kept in a helper with a device-pass guard: the host pass of hipcc silently drops the host stub of a template
 // kernel whose body names this builtin directly.)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 template <int SIZE, typename RSRC>
 __device__ __forceinline__ void dma_to_lds(RSRC rsrc, float* lds, unsigned voff, unsigned soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -141,6 +143,7 @@ struct MCParams {
     int th, nb, tw_log2;             // tile rows per sample, samples per tile, log2(tile width)
     int tiles_x, tiles_y, tiles_b;
     unsigned block_end;              // first logical block id after this segment
+    int wide;                        // PIPE 1: the halo patch is staged in 16-byte pieces (see "wide patch" in the kernel)
   } seg[3];
   int nseg, o_tiles;
   int ksplit, cin_per_split;         // split-K over input channels (tiny layers); partials go to `ws`
@@ -160,17 +163,20 @@ struct MCParams {
   // what the MFMA + operand-fetch loop alone reaches; results are wrong), bit 1 = no barriers in the K loop (wrong too),
   // bit 2 = PIPE 1: issue all DMA pieces of the next chunk up front instead of spreading them over the MFMA stages.
   int debug;
-  // experiments only (FMGAN_MC_CLOCKPTR = device address of 2 x uint64): block 0 adds its shader-clock cycles
+  // experiments only (FMGAN_MC_CLOCKPTR = device address of 16 x uint64): block 0 adds its shader-clock cycles
   // (s_memtime) and its constant-100-MHz ticks (s_memrealtime): their ratio is the clock the chip held during the kernel
   unsigned long long* dbg_clock;
+  int exp_flags;     // experiments only (FMGAN_MC_FLAGS, read per call): bit 0 = set-up and epilogue at wave priority 3
 };
 
 #ifdef FMGAN_EXPERIMENTS
 #define MC_DEBUG(p) ((p).debug)
 #define MC_CLOCK(p) ((p).dbg_clock)
+#define MC_FLAGS(p) ((p).exp_flags)
 #else                                   // product build: the ablation branches fold away
 #define MC_DEBUG(p) 0
 #define MC_CLOCK(p) false
+#define MC_FLAGS(p) 0
 #endif
 
 constexpr int MC_KC = 8;  // input channels per LDS chunk
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   const int l31 = lane & 31, khalf = lane >> 5;
   unsigned long long clk0 = 0, rt0 = 0;
   if (MC_CLOCK(p)) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }
+  if (MC_FLAGS(p) & 1) __builtin_amdgcn_s_setprio(3);
 
   unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
   int si = 0;
@@ -250,7 +257,16 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   const int seg_m_end = p.seg[si].m_off + p.seg[si].gh, seg_n_end = p.seg[si].n_off + p.seg[si].gw;
   constexpr int SP = MODE == 2 ? 2 : 1;          // input step per position
   constexpr int ORG = MODE == 2 ? 0 : 1;         // patch origin = SP * first position - ORG
-  const int TW = 1 << tw_log2, PWP = SP * (TW - 1) + 3;
+  // Wide patch (PIPE 1, unit-step modes, 32-wide tiles of images whose rows are whole 16-byte groups; host decides): the
+  // patch starts FOUR columns left of the tile instead of one and is TW + 8 wide, so every row is ten aligned 16-byte groups,
+  // each either inside the image row or outside it as a whole — one `buffer_load_dwordx4 ... lds` lane moves what four
+  // dword lanes moved.  The short-K layers issue ~3.5x fewer vector-memory instructions per chunk: measured with s_memtime
+  // stamps (profiles/r03_modconv_block_phases.md) a wave of the 1024^2 layer held the matrix pipe 25 % of its K loop with 2.7
+  // waves per SIMD in the loop — it sat in the issue of its DMA pieces, and each epilogue store took ~350 cycles to issue
+  // behind them (vector memory is one in-order pipeline per CU).
+  const bool wide = PIPE == 1 && SP == 1 && p.seg[si].wide != 0;
+  const int XORG = wide ? 4 : ORG;               // patch column c holds image column SP * x0 + c - XORG
+  const int TW = 1 << tw_log2, PWP = wide ? TW + 8 : SP * (TW - 1) + 3;
   const int o_tile = lb % p.o_tiles;
   unsigned pt = lb / p.o_tiles;
   const int tx_i = pt % p.seg[si].tiles_x; pt /= p.seg[si].tiles_x;
@@ -270,8 +286,10 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     const int pos = (wn * RNP + g) * 32 + l31;
     const int tx = pos & (TW - 1), r = pos >> tw_log2;
     const int ty = r % seg_th, nbi = r / seg_th;
-    pbase[g] = nbi * samp + SP * ty * PWP + SP * tx;
-    pos_b[g] = b0 + nbi; pos_y[g] = y0 + ty; pos_x[g] = x0 + tx;
+    // (a thin segment's tile may hold fewer than BN positions — launch_cfg shrinks it until its patch fits the main
+    // segment's LDS image: the rows past nb * th read sample nb - 1's patch and are never stored)
+    pbase[g] = min(nbi, seg_nb - 1) * samp + SP * ty * PWP + SP * tx + (XORG - ORG);
+    pos_b[g] = nbi < seg_nb ? b0 + nbi : p.batch; pos_y[g] = y0 + ty; pos_x[g] = x0 + tx;
   }
 
   f32x16 acc[RM][RNP][NPH];
@@ -300,6 +318,22 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // element offsets are 32-bit, relative to the tile's first sample (host checks nb*cin*h*w < 2^31)
   const float* in_b0 = uniform_ptr(p.in + (long long)b0 * p.cin * hw);
   const float* style_b0 = uniform_ptr(p.style + (long long)b0 * p.cin);
+  // PIPE 1, tiles of one sample: the tile's bias and demodulation values go to LDS now, one vector load per wave, and the
+  // epilogue reads them back with ds_read_b128 — it used to issue 32 two-address vector loads per wave and row group
+  // right when the block's stores want the (in-order, shared) vector-memory pipeline.  Visible to every wave after the
+  // K loop's first barrier.
+  const bool epi_lds = PIPE == 1 && seg_nb == 1 && p.ksplit == 1;
+  float* Es = smem + 2 * p.lds_buf_floats;        // [2][BM]: bias, demod
+  if constexpr (PIPE == 1) {
+    if (epi_lds && tid < 2 * BM) {
+      const bool isd = tid >= BM;
+      const int oc = min(o0 + (isd ? tid - BM : tid), p.cout - 1);
+      float v = isd ? 1.f : 0.f;
+      if (isd) { if (p.demod) v = p.demod[(long long)min(b0, p.batch - 1) * p.cout + oc]; }
+      else if (MODE == 0 && p.fuse_act && p.bias) v = p.bias[oc];
+      Es[tid] = v;
+    }
+  }
   int gofs[NU], lofs[NU], sofs[NU]; bool inb[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -543,6 +577,9 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     }
   };
 
+  unsigned long long clk1 = 0, clk2 = 0, clkw = 0, clke = 0, clkl = 0;
+  if (MC_CLOCK(p)) clk1 = __builtin_readcyclecounter();
+  if (MC_FLAGS(p) & 1) __builtin_amdgcn_s_setprio(0);
   if constexpr (PIPE == 0) {
     if (i_begin < i_end) issue(i_begin);
     for (int i0 = i_begin; i0 < i_end; i0 += KC) {
@@ -556,13 +593,15 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     }
   } else {
     constexpr unsigned PARKED = 0xFFFFFFF0u;
-    constexpr int WSZ = KC * 9 * BM;                        // floats of one weight image
-    constexpr int WPIECES = WSZ / 256;                      // 16-byte pieces (64 lanes x 16 B = 256 floats)
-    static_assert(WSZ % 256 == 0, "weight image = whole DMA pieces");
+    // floats of one weight image, rounded up to whole 16-byte DMA pieces (64 lanes x 16 B = 256 floats; the lanes past the
+    // image are parked and write zeros into the padding)
+    constexpr int WSZ = (KC * 9 * BM + 255) / 256 * 256;
+    constexpr int WPIECES = WSZ / 256;
     constexpr int NWP = (WPIECES + 3) / 4;                  // per wave
     constexpr int NUP = ((KC * (SP * (BNP / 32 - 1) + 3) * (SP * 31 + 3) + 63) / 64 + 3) / 4;   // patch pieces per wave, main tile
     const int xs_total = seg_nb * samp;                     // patch floats
-    const int x_pieces = (xs_total + 63) >> 6;
+    const int x_piece_floats = wide ? 256 : 64;             // one DMA piece = 64 lanes x 16 or 4 bytes
+    const int x_pieces = (xs_total + x_piece_floats - 1) / x_piece_floats;
     const int s_pieces = (seg_nb * KC + 63) >> 6;
     const int bstride = p.lds_buf_floats;
     const bool fastc = fastw && fastx;                      // DMA-servable tensors (chunk completeness checked per chunk)
@@ -574,10 +613,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       const int nbi = e / samp, rem = e - nbi * samp;
       const int kc = rem / plane, q = rem - kc * plane;
       const int r = q / PWP, c = q - r * PWP;
-      const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG;
+      const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - XORG;
       const bool ok = b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w;
       return ok ? (unsigned)(((nbi * p.cin + kc) * p.h + y) * p.w + x) * 4u : PARKED;
     };
+    // wide patch: 16-byte group g16 (four floats, linear LDS index 4 * g16) -> byte offset of its first float, or PARKED;
+    // x is a multiple of 4 and so is p.w (host), so a group never straddles the end of an image row
+    auto x_voff16 = [&](int g16) -> unsigned { return x_voff(4 * g16); };
     auto s_voff = [&](int e) -> unsigned {
       const int nbi = e / KC, kc = e - nbi * KC;
       return (nbi < seg_nb && b0 + nbi < p.batch) ? (unsigned)(nbi * p.cin + kc) * 4u : PARKED;
@@ -587,10 +629,11 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     for (int j = 0; j < NWP; ++j) {
       const int idx = (4 * j + wave) * 64 + lane;           // float4 index in the image [KC*9][BM/4]
       const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-      wvo[j] = (unsigned)((row * p.cout + o0 + c4 * 4) * 4);
+      wvo[j] = idx < KC * 9 * (BM / 4) ? (unsigned)((row * p.cout + o0 + c4 * 4) * 4) : PARKED;
     }
 #pragma unroll
-    for (int u = 0; u < NUP; ++u) xvo[u] = x_voff((4 * u + wave) * 64 + lane);
+    for (int u = 0; u < NUP; ++u)
+      xvo[u] = 4 * u + wave < x_pieces ? (wide ? x_voff16((4 * u + wave) * 64 + lane) : x_voff((4 * u + wave) * 64 + lane)) : PARKED;
     const unsigned svo = s_voff(wave * 64 + lane);          // first style piece of this wave (all of them when nb*KC <= 256)
 
     // This wave's DMA pieces of one chunk, numbered k = 0 .. NPC-1: weights, patch, then the style slice together with
@@ -606,12 +649,16 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
           dma_to_lds<16>(rsrc_w, Wb + (4 * k + wave) * 256, wvo[k < NWP ? k : 0], (unsigned)(i0 * 9 * p.cout * 4));
       } else if (k < NWP + NUP) {
         const int u = k - NWP;
-        if (4 * u + wave < x_pieces)
-          dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], soff_x);
+        if (4 * u + wave < x_pieces) {
+          if (wide) dma_to_lds<16>(rsrc_x, Xb + (4 * u + wave) * 256, xvo[(u >= 0 && u < NUP) ? u : 0], soff_x);
+          else dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], soff_x);
+        }
       } else {
         float* Sb = Xb + p.lds_patch_floats;
-        for (int pc = 4 * NUP + wave; pc < x_pieces; pc += 4)       // patches larger than a main tile's
-          dma_to_lds<4>(rsrc_x, Xb + pc * 64, x_voff(pc * 64 + lane), soff_x);
+        for (int pc = 4 * NUP + wave; pc < x_pieces; pc += 4) {     // patches larger than a main tile's
+          if (wide) dma_to_lds<16>(rsrc_x, Xb + pc * 256, x_voff16(pc * 64 + lane), soff_x);
+          else dma_to_lds<4>(rsrc_x, Xb + pc * 64, x_voff(pc * 64 + lane), soff_x);
+        }
         if (wave < s_pieces)
           dma_to_lds<4>(rsrc_s, Sb + wave * 64, svo, (unsigned)(i0 * 4));
         for (int pc = 4 + wave; pc < s_pieces; pc += 4)
@@ -642,13 +689,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
           }
           *reinterpret_cast<f32x4*>(Wb + idx * 4) = v;
         }
-        for (int e = tid; e < (x_pieces << 6); e += 256) {
+        for (int e = tid; e < x_pieces * x_piece_floats; e += 256) {
           float v = 0.f;
           if (e < xs_total) {
             const int nbi = e / samp, rem = e - nbi * samp;
             const int kc = rem / plane, q = rem - kc * plane;
             const int r = q / PWP, c = q - r * PWP;
-            const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - ORG, i = i0 + kc;
+            const int b = b0 + nbi, y = SP * y0 + r - ORG, x = SP * x0 + c - XORG, i = i0 + kc;
             if (b < p.batch && y >= 0 && y < p.h && x >= 0 && x < p.w && i < i_end)
               v = p.in[(((long long)b * p.cin + i) * p.h + y) * p.w + x];
           }
@@ -680,8 +727,10 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
             dma_to_lds<16>(rsrc_w, Wb + (4 * k + wave) * 256, wvo[k < NWP ? k : 0], (unsigned)(i0 * 9 * p.cout * 4));
         } else if (k < NWP + NUP) {
           const int u = k - NWP;
-          if (4 * u + wave < x_pieces)
-            dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], (unsigned)(i0 * hw * 4));
+          if (4 * u + wave < x_pieces) {
+            if (wide) dma_to_lds<16>(rsrc_x, Xb + (4 * u + wave) * 256, xvo[(u >= 0 && u < NUP) ? u : 0], (unsigned)(i0 * hw * 4));
+            else dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], (unsigned)(i0 * hw * 4));
+          }
         } else if (wave < s_pieces) {
           dma_to_lds<4>(rsrc_s, Xb + p.lds_patch_floats + wave * 64, svo, (unsigned)(i0 * 4));
         }
@@ -690,9 +739,11 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       for (int k = 0; k < NPC; ++k) piece(k, i_begin, 0);
       int bufl = 0;
       for (int i0 = i_begin; i0 < i_end; i0 += KC, bufl ^= 1) {
+        const unsigned long long tw0 = MC_CLOCK(p) ? __builtin_readcyclecounter() : 0;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (MC_CLOCK(p)) clkw += __builtin_readcyclecounter() - tw0;
         const int i1 = i0 + KC;
         const bool more = i1 < i_end;
         Wc = smem + bufl * bstride;
@@ -735,6 +786,8 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     }
   }
 
+  if (MC_CLOCK(p)) clk2 = __builtin_readcyclecounter();
+  if (MC_FLAGS(p) & 1) __builtin_amdgcn_s_setprio(3);
   // ---- epilogue.  All loads first (bias, demod, noise: clamped indices, no branches — a load inside a divergent
   // `if` costs one full memory round trip per element, 64 of them in a row per thread), then arithmetic on the
   // accumulators in place, then predicated stores.
@@ -747,7 +800,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   const int drs = partial ? p.ow : p.out_row_stride;
   const int orow = o0 + wm * 32 * RM + 4 * khalf;     // this lane's first output channel; row r adds (r&3) + 8*(r>>2)
   // per position group: validity, destination, noise term (loaded up front, clamped indices)
-  bool vgs[RNP]; float* dposs[RNP]; float nzs[RNP];
+  bool vgs[RNP]; float nzs[RNP];
 #pragma unroll
   for (int g = 0; g < RNP; ++g) {
     const int b = pos_b[g], bc = min(b, p.batch - 1);
@@ -756,73 +809,150 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
       vgs[g] = b < p.batch && y < p.oh && x < p.ow;
       const int pix = vgs[g] ? y * p.ow + x : 0;
       nzs[g] = (actf && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : bc) * p.oh * p.ow + pix]) : 0.f;
-      dposs[g] = dstbase + (long long)bc * p.cout * dps + (long long)(vgs[g] ? y : 0) * drs + (vgs[g] ? x : 0);
     } else {
       vgs[g] = b < p.batch && pos_y[g] < seg_m_end && pos_x[g] < seg_n_end;
       nzs[g] = 0.f;
-      dposs[g] = dstbase + (long long)bc * p.cout * dps + (long long)(vgs[g] ? 2 * pos_y[g] : 0) * drs + (vgs[g] ? 2 * pos_x[g] : 0);
     }
   }
+  // destination of a position group's first channel (generic store path)
+  auto dpos_of = [&](int g) -> float* {
+    const int bc = min(pos_b[g], p.batch - 1);
+    const int sc = MODE == 1 ? 2 : 1;
+    return dstbase + (long long)bc * p.cout * dps + (long long)(vgs[g] ? sc * pos_y[g] : 0) * drs + (vgs[g] ? sc * pos_x[g] : 0);
+  };
+  // Buffer stores (every tile whose channels all exist and whose samples' output slabs fit 32-bit offsets — every layer of
+  // the model): per-lane byte offset fixed per position group (parked for positions outside the grid: the range check
+  // drops the store), channel / phase row as a scalar offset.  One SALU op + one store per value instead of a 64-bit
+  // multiply-add chain and an exec-mask branch (the generic form below costs ~25 instructions per value).
+  const long long slab = (long long)p.cout * dps * 4;                         // bytes of one sample's output
+  bool bstore = dstbase != nullptr && o0 + BM <= p.cout && (long long)seg_nb * slab < 0xFFFFFFF0LL;
+  if constexpr (MODE == 1) bstore = bstore && 2 * seg_m_end <= p.oh && 2 * seg_n_end <= p.ow;   // every quad complete
+  unsigned vofs[RNP];
+  const float* obase = dstbase ? uniform_ptr(dstbase + (long long)b0 * p.cout * dps) : nullptr;
+  const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(obase), 0,
+      uniform_u32(bstore ? (unsigned)((long long)min(seg_nb, p.batch - b0) * slab) : 0u), 0x00020000);
+#pragma unroll
+  for (int g = 0; g < RNP; ++g) {
+    const long long e = (long long)(pos_b[g] - b0) * p.cout * dps + (long long)(4 * khalf) * dps +
+                        (long long)(MODE == 1 ? 2 * pos_y[g] : pos_y[g]) * drs + (MODE == 1 ? 2 * pos_x[g] : pos_x[g]);
+    vofs[g] = (bstore && vgs[g]) ? (unsigned)(e * 4) : 0xFFFFFFF0u;
+  }
+  // activation constants pinned in SGPRs (left to the compiler they are re-read from the kernel arguments, with a wait,
+  // for every value)
+  unsigned alpha_bits = __float_as_uint(p.alpha), ascale_bits = __float_as_uint(p.act_scale);
+  asm volatile("" : "+s"(alpha_bits), "+s"(ascale_bits));
+  const float alpha = __uint_as_float(alpha_bits), ascale = __uint_as_float(ascale_bits);
+  const unsigned dps4 = uniform_u32((unsigned)(dps * 4)), drs4 = uniform_u32((unsigned)drs * 4u);   // used by bstore only
+  if (MC_CLOCK(p)) clke = __builtin_readcyclecounter();
   // One 32-channel row group at a time: its bias / demodulation values are loaded together (16 + 16 registers live
   // beside the accumulators instead of 32 * RM + 32 * RM: what lets the 128 x 128 tile fit three blocks per CU).
+  auto rows = [&](auto act_c, auto bst_c) {
+    constexpr bool ACT = decltype(act_c)::value, BST = decltype(bst_c)::value;
 #pragma unroll
-  for (int m = 0; m < RM; ++m) {
-    float bias_m[16], dm_m[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
-      bias_m[r] = (actf && p.bias) ? p.bias[oc] : 0.f;
-      dm_m[r] = 1.f;
-    }
-#pragma unroll
-    for (int g = 0; g < RNP; ++g) {
-      const int bc = min(pos_b[g], p.batch - 1);
-      if (use_demod && (g == 0 || seg_nb > 1)) {        // tiles of one sample (every large layer) load demod once
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          dm_m[r] = p.demod[(long long)bc * p.cout + min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1)];
-      }
-      const bool vg = vgs[g];
-      float* dpos = dposs[g];
-      if constexpr (MODE != 1) {
-        const float nz = nzs[g];
+    for (int m = 0; m < RM; ++m) {
+      float bias_m[16], dm_m[16];
+      if (epi_lds) {
+        const float* eb = Es + (orow - o0) + m * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc[m][g][0][r] * dm_m[r];
-          if (actf) {
-            v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
-            v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
-          }
-          if constexpr (RGB) acc[m][g][0][r] = (vg && o < p.cout) ? v : 0.f;
-          if ((!RGB || dstbase) && vg && o < p.cout) dpos[(long long)o * dps] = v;
+          bias_m[r] = ACT ? eb[(r & 3) + 8 * (r >> 2)] : 0.f;
+          dm_m[r] = eb[BM + (r & 3) + 8 * (r >> 2)];
         }
       } else {
-        const int X = 2 * pos_x[g], Y0 = 2 * pos_y[g];
-        const bool pair = X + 1 < p.ow;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
-          if (!(vg && o < p.cout)) continue;
-          float* dst = dpos + (long long)o * dps;
+          const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
+          bias_m[r] = (ACT && p.bias) ? p.bias[oc] : 0.f;
+          dm_m[r] = 1.f;
+        }
+      }
+      const unsigned so_m = (unsigned)(o0 + wm * 32 * RM + m * 32) * dps4;     // scalar: first channel of the row group
 #pragma unroll
-          for (int py = 0; py < 2; ++py) {
-            if (Y0 + py >= p.oh) continue;
-            const float v0 = acc[m][g][py * 2][r] * dm_m[r], v1 = acc[m][g][py * 2 + 1][r] * dm_m[r];
-            if (pair) {
-              f32x2_u t; t.x = v0; t.y = v1;
-              *reinterpret_cast<f32x2_u*>(dst + (long long)py * drs) = t;
+      for (int g = 0; g < RNP; ++g) {
+        const int bc = min(pos_b[g], p.batch - 1);
+        if (!epi_lds && use_demod && (g == 0 || seg_nb > 1)) {        // tiles of one sample (every large layer) load demod once
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dm_m[r] = p.demod[(long long)bc * p.cout + min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1)];
+        }
+        const bool vg = vgs[g];
+        float* dpos = BST ? nullptr : dpos_of(g);
+        if (MC_CLOCK(p) && m == 0 && g == 0) {          // every load of the epilogue has landed (stamps only)
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_waitcnt(0);
+          clkl = __builtin_readcyclecounter();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MODE != 1) {
+          const float nz = nzs[g];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[m][g][0][r] * dm_m[r];
+            if constexpr (ACT) {
+              v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
+              v = (v > 0.f ? v : v * alpha) * ascale;
+            }
+            if constexpr (BST) {
+              if constexpr (RGB) acc[m][g][0][r] = vg ? v : 0.f;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_o, vofs[g], so_m + (unsigned)((r & 3) + 8 * (r >> 2)) * dps4, 0);
             } else {
-              dst[(long long)py * drs] = v0;
+              if constexpr (RGB) acc[m][g][0][r] = (vg && o < p.cout) ? v : 0.f;
+              if ((!RGB || dstbase) && vg && o < p.cout) dpos[(long long)o * dps] = v;
+            }
+          }
+        } else {
+          const int X = 2 * pos_x[g], Y0 = 2 * pos_y[g];
+          const bool pair = X + 1 < p.ow;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+            if constexpr (BST) {
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                u32x2 t;
+                t.x = __float_as_uint(acc[m][g][py * 2][r] * dm_m[r]);
+                t.y = __float_as_uint(acc[m][g][py * 2 + 1][r] * dm_m[r]);
+                __builtin_amdgcn_raw_buffer_store_b64(t, rsrc_o, vofs[g], so_m + (unsigned)((r & 3) + 8 * (r >> 2)) * dps4 + (unsigned)py * drs4, 0);
+              }
+            } else {
+              if (!(vg && o < p.cout)) continue;
+              float* dst = dpos + (long long)o * dps;
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                if (Y0 + py >= p.oh) continue;
+                const float v0 = acc[m][g][py * 2][r] * dm_m[r], v1 = acc[m][g][py * 2 + 1][r] * dm_m[r];
+                if (pair) {
+                  f32x2_u t; t.x = v0; t.y = v1;
+                  *reinterpret_cast<f32x2_u*>(dst + (long long)py * drs) = t;
+                } else {
+                  dst[(long long)py * drs] = v0;
+                }
+              }
             }
           }
         }
       }
     }
+  };
+  if (bstore) {
+    if (actf) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{});
+  } else {
+    if (actf) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{});
   }
   if (MC_CLOCK(p) && tid == 0 && (blockIdx.x & 63) == 0) {
-    atomicAdd(p.dbg_clock, __builtin_readcyclecounter() - clk0);
+    const unsigned long long clk3 = __builtin_readcyclecounter();
+    atomicAdd(p.dbg_clock, clk3 - clk0);
     atomicAdd(p.dbg_clock + 1, wall_clock64() - rt0);
+    atomicAdd(p.dbg_clock + 2, clk1 - clk0);       // set-up (tile decode, staging plan)
+    atomicAdd(p.dbg_clock + 3, clk2 - clk1);       // first chunk's wait + K loop
+    atomicAdd(p.dbg_clock + 4, clk3 - clk2);       // epilogue up to the last store's issue
+    atomicAdd(p.dbg_clock + 5, 1ULL);
+    atomicAdd(p.dbg_clock + 8, clkl - clke);       // of the epilogue: waiting for bias / demod / noise
+    __builtin_amdgcn_s_waitcnt(0);
+    atomicAdd(p.dbg_clock + 9, __builtin_readcyclecounter() - clk3);   // after the last store's issue: until all are acknowledged
+    atomicAdd(p.dbg_clock + 7, clke - clk2);       // of the epilogue: destinations, validity, noise loads issued
+    atomicAdd(p.dbg_clock + 6, clkw);               // of the K loop: waiting for the chunk's DMA + barrier (lean loop)
   }
   if constexpr (RGB) {
     // second pass over the activated values (now in the accumulators): rgb = sum over rows of act * wmod, where
@@ -912,6 +1042,16 @@ inline int pick_tw_log2(int gw, int gh) {
   return gw <= 4 ? 2 : (gw <= 8 ? 3 : (gw <= 16 ? 4 : 5));
 }
 
+// experiments build: FMGAN_MC_WIDE=0 keeps the 4-byte patch pieces (A/B measurements); product: always on
+inline bool mc_wide_patch() {
+#ifdef FMGAN_EXPERIMENTS
+  const char* e = getenv("FMGAN_MC_WIDE");
+  return !(e && e[0] == '0');
+#else
+  return true;
+#endif
+}
+
 // tile plan of one segment; returns its block count (without the o_tiles factor) and LDS floats for the patch
 inline long long plan_segment(MCParams::Seg& sg, int batch, int BN) {
   sg.tw_log2 = pick_tw_log2(sg.gw, sg.gh);
@@ -943,24 +1083,52 @@ int launch_cfg(MCParams& p, hipStream_t s) {
   p.o_tiles = (p.cout + BM - 1) / BM;
   long long blocks = 0;
   size_t patch = 0, nbmax = 1;
+  // LDS floats of a segment's halo patch (wide patch: rows of whole, aligned 16-byte groups — see the kernel)
+  auto patch_floats = [&](const MCParams::Seg& sg) {
+    size_t f = (size_t)sg.nb * KC * (SP * (sg.th - 1) + 3) * (sg.wide ? (1 << sg.tw_log2) + 8 : SP * ((1 << sg.tw_log2) - 1) + 3);
+    return sg.wide ? (f + 255) / 256 * 256 : f;             // whole 64-lane x 16-byte pieces
+  };
+  long long seg_blocks[3] = {0, 0, 0};
+  int main_seg = 0;
   for (int i = 0; i < p.nseg; ++i) {
-    blocks += plan_segment(p.seg[i], p.batch, BN) * p.o_tiles;
+    seg_blocks[i] = plan_segment(p.seg[i], p.batch, BN);
+    if (seg_blocks[i] > seg_blocks[main_seg]) main_seg = i;
+    p.seg[i].wide = PIPE == 1 && SP == 1 && p.seg[i].tw_log2 == 5 && (p.seg[i].n_off & 3) == 0 && (p.w & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && mc_wide_patch();
+  }
+  // The LDS image is sized by the largest patch of the launch and decides how many blocks a CU holds.  The thin segments of
+  // the transposed conv (one row / one column of quads) pack samples or rows into their tiles and used to need twice the
+  // main segment's patch — one block per CU less for the whole layer.  They now take smaller tiles (fewer samples, then
+  // fewer rows, per tile: part of the tile's positions stay empty) until their patch fits the main segment's.
+  // (Only for launches of several rounds of blocks: there the thin segments are < 1 % of the blocks.  A small layer runs in
+  // one round, and four times as many mostly-empty strip blocks with full-length K loops cost it 25 %: 8^2, 16^2 at B = 8.)
+  const size_t main_patch = patch_floats(p.seg[main_seg]);
+  const bool cap_strips = seg_blocks[main_seg] * p.o_tiles >= 4LL * FMGAN_NUM_CU;
+  for (int i = 0; i < p.nseg; ++i) {
+    MCParams::Seg& sg = p.seg[i];
+    while (cap_strips && i != main_seg && patch_floats(sg) > main_patch && (sg.nb > 1 || sg.th > 1)) {
+      if (sg.nb > 1) sg.nb >>= 1; else sg.th >>= 1;
+      sg.tiles_y = (sg.gh + sg.th - 1) / sg.th;
+      sg.tiles_b = (p.batch + sg.nb - 1) / sg.nb;
+      seg_blocks[i] = (long long)sg.tiles_x * sg.tiles_y * sg.tiles_b;
+    }
+    blocks += seg_blocks[i] * p.o_tiles;
     if (blocks > 0x7fffffffLL) return FMGAN_EOVERFLOW;
-    p.seg[i].block_end = (unsigned)blocks;
+    sg.block_end = (unsigned)blocks;
     // 32-bit in-tile element offsets: (samples of a tile that exist) x cin x h x w must fit.  (Slots of a tile's
     // samples beyond the batch are never addressed: their offsets are parked / their loads masked.)
-    const int nb_live = p.seg[i].nb < p.batch ? p.seg[i].nb : p.batch;
+    const int nb_live = sg.nb < p.batch ? sg.nb : p.batch;
     if ((long long)nb_live * p.cin * p.h * p.w >= (1LL << 31)) return FMGAN_EOVERFLOW;
-    const size_t f = (size_t)p.seg[i].nb * KC * (SP * (p.seg[i].th - 1) + 3) * (SP * ((1 << p.seg[i].tw_log2) - 1) + 3);
+    const size_t f = patch_floats(sg);
     if (f > patch) patch = f;
-    if ((size_t)p.seg[i].nb > nbmax) nbmax = p.seg[i].nb;
+    if ((size_t)sg.nb > nbmax) nbmax = sg.nb;
   }
   size_t lds = sizeof(float) * ((size_t)KC * 9 * BM + patch);
   if constexpr (PIPE == 1) {
     if (p.cin_per_split % KC != 0) return 1;
     p.lds_patch_floats = (int)((patch + 63) / 64 * 64);
-    p.lds_buf_floats = KC * 9 * BM + p.lds_patch_floats + (int)((nbmax * KC + 63) / 64 * 64);
-    lds = sizeof(float) * 2 * (size_t)p.lds_buf_floats;
+    p.lds_buf_floats = (KC * 9 * BM + 255) / 256 * 256 + p.lds_patch_floats + (int)((nbmax * KC + 63) / 64 * 64);
+    lds = sizeof(float) * (2 * (size_t)p.lds_buf_floats + 2 * BM);     // + this tile's bias and demodulation values
     if (lds > (MINB == 1 ? MC_LDS_MAX : MC_LDS_LIMIT)) return 1;
     if (lds > MC_LDS_LIMIT) {
       // one block per CU may use more than the 64 KB a launch gets by default (160 KB per CU on gfx950)
@@ -992,28 +1160,24 @@ int launch_cfg(MCParams& p, hipStream_t s) {
 // FMGAN_MC_CLOCKPTR; the product library has no environment switch and no ablation code path.
 inline char mc_variant(int mode, int cfg) {
 #ifndef FMGAN_EXPERIMENTS
-  static const char defaults[3][3] = {{'C', 'C', 'C'}, {'A', 'B', 'B'}, {'A', 'A', 'A'}};   // comments: see below
+  static const char defaults[3][3] = {{'C', 'C', 'D'}, {'A', 'B', 'D'}, {'A', 'A', 'A'}};   // comments: see below
   return defaults[mode][cfg];
 #else
-  static char table[3][3];
-  static bool init = false;
-  if (!init) {
-    // measured on MI355X (profiles/r02_modconv_variants.md): plain conv, Cout >= 96: 128 x 256 tile by LDS-DMA (C);
-    // Cout >= 48: 64 x 256 in 4-channel chunks, three blocks per CU (C; 1470 -> 1390 us at 512^2 against 8-channel chunks
-    // at two blocks per CU, possible since the scalar wave index freed ~25 VGPRs); Cout < 48: 32 x 256, three blocks per CU
-    // (C: 1701 us at 1024^2; 32 x 128 by LDS-DMA 1809, register pipeline 1760-1790, 32 x 512 1873);
-    // transposed conv: LDS-DMA (B) for every width (a 4-block form of its 32-channel tile spills and loses 2 %)
-    const char defaults[3][3] = {{'C', 'C', 'C'}, {'A', 'B', 'B'}, {'A', 'A', 'A'}};
-    for (int m = 0; m < 3; ++m)
-      for (int c = 0; c < 3; ++c) {
-        char name[32];
-        snprintf(name, sizeof(name), "FMGAN_MC_V%d%d", m, c);
-        const char* e = getenv(name);
-        table[m][c] = (e && e[0] >= 'A' && e[0] <= 'C') ? e[0] : defaults[m][c];
-      }
-    init = true;
-  }
-  return table[mode][cfg];
+  // (read per call: the A/B tools sweep variants inside one process)
+  // measured on MI355X (profiles/r02_modconv_variants.md): plain conv, Cout >= 96: 128 x 256 tile by LDS-DMA (C);
+  // Cout >= 48: 64 x 256 in 4-channel chunks, three blocks per CU (C; 1470 -> 1390 us at 512^2 against 8-channel chunks
+  // at two blocks per CU, possible since the scalar wave index freed ~25 VGPRs); Cout < 48: 32 x 256, three blocks per CU
+  // (C: 1701 us at 1024^2; 32 x 128 by LDS-DMA 1809, register pipeline 1760-1790, 32 x 512 1873);
+  // transposed conv: LDS-DMA (B) for every width.
+  // Round 3 (profiles/r03_modconv_block_phases.md, r03_modconv_layers_ab.md), after the wide patch and the buffer-store
+  // epilogue: Cout < 48 plain: 32 x 256 in 4-channel chunks (D: 24 KB of LDS and 96 registers, 5 blocks per CU instead of
+  // 3; 1446 -> 1373 us at 1024^2, with the fused ToRGB 1852 -> 1817); transposed 32-channel tile in a 128-register budget
+  // (D: 4 blocks per CU instead of 3, 8 spilled dwords in the epilogue; 785 -> 757 us at 512^2).
+  const char defaults[3][3] = {{'C', 'C', 'D'}, {'A', 'B', 'D'}, {'A', 'A', 'A'}};
+  char name[32];
+  snprintf(name, sizeof(name), "FMGAN_MC_V%d%d", mode, cfg);
+  const char* e = getenv(name);
+  return (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] : defaults[mode][cfg];
 #endif
 }
 
@@ -1070,6 +1234,10 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
     if (cfg < 2 && (small || p.rgb_out)) v = (!p.rgb_out && (long long)p.batch * p.h * p.w >= 1536) ? 'B' : 'A';
     else if (cfg == 2 && small) v = 'B';
   }
+  if (mode == 0 && v == 'D') {
+    const bool small = p.ksplit > 1 || blocks_with(p, 32, 256) < 2LL * FMGAN_NUM_CU;
+    if (small) v = 'B';
+  }
   int st = 1;
   if (mode == 0) {
     switch (cfg) {
@@ -1084,6 +1252,7 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
       default:
         if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
         else if (v == 'C') st = launch_cfg<0, 1, 2, 1, 4, 3, 8, 1>(p, s);                      // 32 x 256, 3 blocks per CU
+        else if (v == 'D') st = launch_cfg<0, 1, 2, 1, 4, 5, 4, 1>(p, s);                      // 32 x 256, 4-channel chunks: 5-6 blocks per CU
         return st != 1 ? st : launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
     }
   }
@@ -1101,6 +1270,7 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
   }
   if (v == 'B') st = launch_cfg<1, 1, 1, 1, 4, 3, 8, 1>(p, s);
   else if (v == 'C') st = launch_cfg<1, 1, 2, 1, 4, 2, 8, 1>(p, s);
+  else if (v == 'D') st = launch_cfg<1, 1, 1, 1, 4, 4, 8, 1>(p, s);                            // as B in a 128-register budget: 4 blocks per CU
   return st != 1 ? st : launch_cfg<1, 1, 1, 1, 4, 3>(p, s);
 }
 
@@ -1773,6 +1943,7 @@ int modconv2d_impl(const float* in, const float* wt, const float* style, const f
     static long long clk = -1;
     if (clk < 0) { const char* e = getenv("FMGAN_MC_CLOCKPTR"); clk = e ? atoll(e) : 0; }
     p.dbg_clock = (unsigned long long*)clk;
+    { const char* e = getenv("FMGAN_MC_FLAGS"); p.exp_flags = e ? atoi(e) : 0; }
   }
 #endif
   if (rgb) {
