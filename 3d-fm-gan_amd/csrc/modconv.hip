@@ -159,6 +159,7 @@ struct MCParams {
   // PIPE 1 (all staging by LDS-DMA): floats per LDS buffer = weights + patch region + style region, and the patch
   // region's size (both rounded to 64 floats so every DMA piece of 64 lanes x 4 B stays inside its region)
   int lds_buf_floats, lds_patch_floats;
+  int lds_style_floats;              // PIPE 1: > 0 = the tile's whole style slice [cin_per_split] is staged once, behind bias/demod
   // experiments only (FMGAN_MC_DEBUG, tools/bench_conv_variants.py --debug): bit 0 = stage the first chunk only (ablation:
   // what the MFMA + operand-fetch loop alone reaches; results are wrong), bit 1 = no barriers in the K loop (wrong too),
   // bit 2 = PIPE 1: issue all DMA pieces of the next chunk up front instead of spreading them over the MFMA stages.
@@ -322,16 +323,18 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
   // epilogue reads them back with ds_read_b128 — it used to issue 32 two-address vector loads per wave and row group
   // right when the block's stores want the (in-order, shared) vector-memory pipeline.  Visible to every wave after the
   // K loop's first barrier.
+  // (The load is issued here and its value written to LDS after the first chunk's DMA pieces are out, so its latency hides
+  // under the wait for that chunk.)
   const bool epi_lds = PIPE == 1 && seg_nb == 1 && p.ksplit == 1;
   float* Es = smem + 2 * p.lds_buf_floats;        // [2][BM]: bias, demod
+  float epi_v = 0.f;
   if constexpr (PIPE == 1) {
     if (epi_lds && tid < 2 * BM) {
       const bool isd = tid >= BM;
       const int oc = min(o0 + (isd ? tid - BM : tid), p.cout - 1);
-      float v = isd ? 1.f : 0.f;
-      if (isd) { if (p.demod) v = p.demod[(long long)min(b0, p.batch - 1) * p.cout + oc]; }
-      else if (MODE == 0 && p.fuse_act && p.bias) v = p.bias[oc];
-      Es[tid] = v;
+      epi_v = isd ? 1.f : 0.f;
+      if (isd) { if (p.demod) epi_v = p.demod[(long long)min(b0, p.batch - 1) * p.cout + oc]; }
+      else if (MODE == 0 && p.fuse_act && p.bias) epi_v = p.bias[oc];
     }
   }
   int gofs[NU], lofs[NU], sofs[NU]; bool inb[NU];
@@ -718,6 +721,8 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
     // the 17 layers — and 24-31 more spilled SGPRs; not kept.)
     const bool lean = fastc && MC_DEBUG(p) == 0 && i_begin < i_end && ((i_end - i_begin) % KC) == 0 && x_pieces <= 4 * NUP &&
                       s_pieces <= 4 && tapmask == 0x1FFu;
+    const bool style_once = lean && seg_nb == 1 && p.lds_style_floats > 0;
+    float* Ss = Es + 2 * BM;
     if (lean) {
       auto piece = [&](int k, int i0, int bufi) {
         float* Wb = smem + bufi * bstride;
@@ -731,12 +736,24 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
             if (wide) dma_to_lds<16>(rsrc_x, Xb + (4 * u + wave) * 256, xvo[(u >= 0 && u < NUP) ? u : 0], (unsigned)(i0 * hw * 4));
             else dma_to_lds<4>(rsrc_x, Xb + (4 * u + wave) * 64, xvo[(u >= 0 && u < NUP) ? u : 0], (unsigned)(i0 * hw * 4));
           }
-        } else if (wave < s_pieces) {
+        } else if (!style_once && wave < s_pieces) {
           dma_to_lds<4>(rsrc_s, Xb + p.lds_patch_floats + wave * 64, svo, (unsigned)(i0 * 4));
         }
       };
+      // style slice of the whole K range, once (one DMA piece per wave and chunk less; the loads fly with the first chunk)
+      float sty0 = 0.f, sty1 = 0.f;
+      if (style_once) {
+        const int n = i_end - i_begin;
+        if (tid < n) sty0 = style_b0[i_begin + tid];
+        if (tid + 256 < n) sty1 = style_b0[i_begin + tid + 256];
+      }
 #pragma unroll
       for (int k = 0; k < NPC; ++k) piece(k, i_begin, 0);
+      if (epi_lds && tid < 2 * BM) Es[tid] = epi_v;
+      if (style_once) {
+        if (tid < p.lds_style_floats) Ss[tid] = sty0;
+        if (tid + 256 < p.lds_style_floats) Ss[tid + 256] = sty1;
+      }
       int bufl = 0;
       for (int i0 = i_begin; i0 < i_end; i0 += KC, bufl ^= 1) {
         const unsigned long long tw0 = MC_CLOCK(p) ? __builtin_readcyclecounter() : 0;
@@ -748,7 +765,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
         const bool more = i1 < i_end;
         Wc = smem + bufl * bstride;
         Xc = Wc + WSZ;
-        Sc = Xc + p.lds_patch_floats;
+        Sc = style_once ? Ss + (i0 - i_begin) : Xc + p.lds_patch_floats;
         contract([&](int st) {
           if (more) {
 #pragma unroll
@@ -758,7 +775,10 @@ __global__ __launch_bounds__(256, MINB) void modconv_mfma_f32(const MCParams p) 
         }, std::true_type{});
       }
     }
-    if (!lean && i_begin < i_end) stage(i_begin, 0);
+    if (!lean && i_begin < i_end) {
+      stage(i_begin, 0);
+      if (epi_lds && tid < 2 * BM) Es[tid] = epi_v;
+    }
     int buf = 0;
     for (int i0 = lean ? i_end : i_begin; i0 < i_end; i0 += KC, buf ^= 1) {
       // this wave's DMA pieces / LDS stores of chunk i0 have landed; after the barrier everyone's have, and every wave
@@ -1128,7 +1148,9 @@ int launch_cfg(MCParams& p, hipStream_t s) {
     if (p.cin_per_split % KC != 0) return 1;
     p.lds_patch_floats = (int)((patch + 63) / 64 * 64);
     p.lds_buf_floats = (KC * 9 * BM + 255) / 256 * 256 + p.lds_patch_floats + (int)((nbmax * KC + 63) / 64 * 64);
-    lds = sizeof(float) * (2 * (size_t)p.lds_buf_floats + 2 * BM);     // + this tile's bias and demodulation values
+    // + this tile's bias and demodulation values + (tiles of one sample, <= 512 input channels) its style slice, staged once
+    p.lds_style_floats = (nbmax == 1 && p.cin_per_split <= 512) ? p.cin_per_split : 0;
+    lds = sizeof(float) * (2 * (size_t)p.lds_buf_floats + 2 * BM + p.lds_style_floats);
     if (lds > (MINB == 1 ? MC_LDS_MAX : MC_LDS_LIMIT)) return 1;
     if (lds > MC_LDS_LIMIT) {
       // one block per CU may use more than the 64 KB a launch gets by default (160 KB per CU on gfx950)

@@ -29,7 +29,10 @@
 //     the MFMA launch far less.
 // Shapes it serves: cin % 16 == 0, cout % 32 == 0, position grid at least 32 wide; everything else returns
 // FMGAN_EUNSUPPORTED and the caller keeps the fp32 kernel (the 4^2..16^2 layers: < 3 % of the FLOPs at B=8).
+#include <type_traits>
 #include "common.h"
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -263,61 +266,97 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_bf16(const BFParams p) {
     }
   }
 
-  // ---- epilogue (the fp32 kernel's: loads first, arithmetic in place, predicated stores)
+  // ---- epilogue (the fp32 kernel's: loads first, arithmetic in place; stores through a buffer resource — per-lane byte
+  // offset fixed per position group and parked for positions outside the grid, channel / phase row as a scalar offset —
+  // whenever the tile's channels all exist, the sample's output fits 32-bit offsets and, MODE 1, every quad of the tile is
+  // complete; the generic predicated stores otherwise)
   const bool actf = MODE == 0 && p.fuse_act;
   const float nw = (actf && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
   const int orow = o0 + 4 * khalf;          // row r of a 32-row group adds (r&3) + 8*(r>>2)
   float* dst_b = p.out + (long long)b * p.cout * p.out_plane_stride;
+  const long long dps = p.out_plane_stride;
+  const int drs = p.out_row_stride;
+  const long long slab = (long long)p.cout * dps * 4;
+  constexpr int TH_ = 4 * RNP;
+  bool bstore = o0 + 32 * RM <= p.cout && slab < 0xFFFFFFF0LL;
+  if constexpr (MODE == 1) bstore = bstore && y0 + TH_ <= p.h && x0 + 32 <= p.w;
+  const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(dst_b, 0, bstore ? (unsigned)slab : 0u, 0x00020000);
+  unsigned alpha_bits = __float_as_uint(p.alpha), ascale_bits = __float_as_uint(p.act_scale);
+  asm volatile("" : "+s"(alpha_bits), "+s"(ascale_bits));
+  const float alpha = __uint_as_float(alpha_bits), ascale = __uint_as_float(ascale_bits);
+  const unsigned dps4 = (unsigned)(dps * 4), drs4 = (unsigned)drs * 4u;
+  auto rows = [&](auto act_c, auto bst_c) {
+    constexpr bool ACT = decltype(act_c)::value, BST = decltype(bst_c)::value;
 #pragma unroll
-  for (int m = 0; m < RM; ++m) {
-    float bias_m[16], dm_m[16];
+    for (int m = 0; m < RM; ++m) {
+      float bias_m[16], dm_m[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
-      bias_m[r] = (actf && p.bias) ? p.bias[oc] : 0.f;
-      dm_m[r] = p.demod ? p.demod[(long long)b * p.cout + oc] : 1.f;
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
+        bias_m[r] = (ACT && p.bias) ? p.bias[oc] : 0.f;
+        dm_m[r] = p.demod ? p.demod[(long long)b * p.cout + oc] : 1.f;
+      }
+      const unsigned so_m = (unsigned)(o0 + m * 32) * dps4;
 #pragma unroll
-    for (int g = 0; g < RNP; ++g) {
-      const int py_ = y0 + wave * RNP + g, px_ = x0 + l31;       // position
-      const bool vg = py_ < p.gh && px_ < p.gw;
-      if constexpr (MODE != 1) {
-        const int pix = vg ? py_ * p.ow + px_ : 0;
-        const float nz = (actf && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * p.oh * p.ow + pix]) : 0.f;
-        float* dpos = dst_b + (long long)(vg ? py_ : 0) * p.out_row_stride + (vg ? px_ : 0);
+      for (int g = 0; g < RNP; ++g) {
+        const int py_ = y0 + wave * RNP + g, px_ = x0 + l31;       // position
+        const bool vg = py_ < p.gh && px_ < p.gw;
+        constexpr int SC = MODE == 1 ? 2 : 1;
+        const unsigned vof = (BST && vg) ? (unsigned)(((long long)(4 * khalf) * dps + (long long)(SC * py_) * drs + SC * px_) * 4) : 0xFFFFFFF0u;
+        if constexpr (MODE != 1) {
+          const int pix = vg ? py_ * p.ow + px_ : 0;
+          const float nz = (ACT && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * p.oh * p.ow + pix]) : 0.f;
+          float* dpos = dst_b + (long long)(vg ? py_ : 0) * p.out_row_stride + (vg ? px_ : 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc[m][g][0][r] * dm_m[r];
-          if (actf) {
-            v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
-            v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
+          for (int r = 0; r < 16; ++r) {
+            const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[m][g][0][r] * dm_m[r];
+            if constexpr (ACT) {
+              v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
+              v = (v > 0.f ? v : v * alpha) * ascale;
+            }
+            if constexpr (BST) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_o, vof, so_m + (unsigned)((r & 3) + 8 * (r >> 2)) * dps4, 0);
+            else if (vg && o < p.cout) dpos[(long long)o * p.out_plane_stride] = v;
           }
-          if (vg && o < p.cout) dpos[(long long)o * p.out_plane_stride] = v;
-        }
-      } else {
-        float* dpos = dst_b + (long long)(vg ? 2 * py_ : 0) * p.out_row_stride + (vg ? 2 * px_ : 0);
-        const bool pair = 2 * px_ + 1 < p.ow;          // position n = w owns the last output column only
+        } else {
+          float* dpos = dst_b + (long long)(vg ? 2 * py_ : 0) * p.out_row_stride + (vg ? 2 * px_ : 0);
+          const bool pair = 2 * px_ + 1 < p.ow;          // position n = w owns the last output column only
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
-          if (!(vg && o < p.cout)) continue;
-          float* dst = dpos + (long long)o * p.out_plane_stride;
+          for (int r = 0; r < 16; ++r) {
+            const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+            if constexpr (BST) {
 #pragma unroll
-          for (int py = 0; py < 2; ++py) {
-            if (2 * py_ + py >= p.oh) continue;          // position m = h owns the last output row only
-            const float v0 = acc[m][g][py * 2][r] * dm_m[r], v1 = acc[m][g][py * 2 + 1][r] * dm_m[r];
-            if (pair) {
-              f32x2_u t;
-              t.x = v0; t.y = v1;
-              *reinterpret_cast<f32x2_u*>(dst + (long long)py * p.out_row_stride) = t;
+              for (int py = 0; py < 2; ++py) {
+                u32x2 t;
+                t.x = __float_as_uint(acc[m][g][py * 2][r] * dm_m[r]);
+                t.y = __float_as_uint(acc[m][g][py * 2 + 1][r] * dm_m[r]);
+                __builtin_amdgcn_raw_buffer_store_b64(t, rsrc_o, vof, so_m + (unsigned)((r & 3) + 8 * (r >> 2)) * dps4 + (unsigned)py * drs4, 0);
+              }
             } else {
-              dst[(long long)py * p.out_row_stride] = v0;
+              if (!(vg && o < p.cout)) continue;
+              float* dst = dpos + (long long)o * p.out_plane_stride;
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                if (2 * py_ + py >= p.oh) continue;          // position m = h owns the last output row only
+                const float v0 = acc[m][g][py * 2][r] * dm_m[r], v1 = acc[m][g][py * 2 + 1][r] * dm_m[r];
+                if (pair) {
+                  f32x2_u t;
+                  t.x = v0; t.y = v1;
+                  *reinterpret_cast<f32x2_u*>(dst + (long long)py * p.out_row_stride) = t;
+                } else {
+                  dst[(long long)py * p.out_row_stride] = v0;
+                }
+              }
             }
           }
         }
       }
     }
+  };
+  if (bstore) {
+    if (actf) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{});
+  } else {
+    if (actf) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{});
   }
 }
 
@@ -570,55 +609,91 @@ __global__ __launch_bounds__(256, 2) void modconv_mfma_bf16x3(const BFParams p) 
   // ---- epilogue (as modconv_mfma_bf16 with RM = 1)
   const bool actf = MODE == 0 && p.fuse_act;
   const float nw = (actf && p.noise && p.noise_weight) ? p.noise_weight[0] : 0.f;
-  const int orow = o0 + 4 * khalf;
+  const int orow = o0 + 4 * khalf;          // row r of a 32-row group adds (r&3) + 8*(r>>2)
   float* dst_b = p.out + (long long)b * p.cout * p.out_plane_stride;
-  float bias_m[16], dm_m[16];
+  const long long dps = p.out_plane_stride;
+  const int drs = p.out_row_stride;
+  const long long slab = (long long)p.cout * dps * 4;
+  constexpr int TH_ = 4 * RNP;
+  bool bstore = o0 + 32 <= p.cout && slab < 0xFFFFFFF0LL;
+  if constexpr (MODE == 1) bstore = bstore && y0 + TH_ <= p.h && x0 + 32 <= p.w;
+  const auto rsrc_o = __builtin_amdgcn_make_buffer_rsrc(dst_b, 0, bstore ? (unsigned)slab : 0u, 0x00020000);
+  unsigned alpha_bits = __float_as_uint(p.alpha), ascale_bits = __float_as_uint(p.act_scale);
+  asm volatile("" : "+s"(alpha_bits), "+s"(ascale_bits));
+  const float alpha = __uint_as_float(alpha_bits), ascale = __uint_as_float(ascale_bits);
+  const unsigned dps4 = (unsigned)(dps * 4), drs4 = (unsigned)drs * 4u;
+  auto rows = [&](auto act_c, auto bst_c) {
+    constexpr bool ACT = decltype(act_c)::value, BST = decltype(bst_c)::value;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int oc = min(orow + (r & 3) + 8 * (r >> 2), p.cout - 1);
-    bias_m[r] = (actf && p.bias) ? p.bias[oc] : 0.f;
-    dm_m[r] = p.demod ? p.demod[(long long)b * p.cout + oc] : 1.f;
-  }
-#pragma unroll
-  for (int g = 0; g < RNP; ++g) {
-    const int py_ = y0 + wave * RNP + g, px_ = x0 + l31;
-    const bool vg = py_ < p.gh && px_ < p.gw;
-    if constexpr (MODE == 0) {
-      const int pix = vg ? py_ * p.ow + px_ : 0;
-      const float nz = (actf && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * p.oh * p.ow + pix]) : 0.f;
-      float* dpos = dst_b + (long long)(vg ? py_ : 0) * p.out_row_stride + (vg ? px_ : 0);
+    for (int m = 0; m < 1; ++m) {
+      float bias_m[16], dm_m[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = orow + (r & 3) + 8 * (r >> 2);
-        float v = acc[g][0][r] * dm_m[r];
-        if (actf) {
-          v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
-          v = (v > 0.f ? v : v * p.alpha) * p.act_scale;
-        }
-        if (vg && o < p.cout) dpos[(long long)o * p.out_plane_stride] = v;
+        const int oc = min(orow + m * 32 + (r & 3) + 8 * (r >> 2), p.cout - 1);
+        bias_m[r] = (ACT && p.bias) ? p.bias[oc] : 0.f;
+        dm_m[r] = p.demod ? p.demod[(long long)b * p.cout + oc] : 1.f;
       }
-    } else {
-      float* dpos = dst_b + (long long)(vg ? 2 * py_ : 0) * p.out_row_stride + (vg ? 2 * px_ : 0);
-      const bool pair = 2 * px_ + 1 < p.ow;
+      const unsigned so_m = (unsigned)(o0 + m * 32) * dps4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = orow + (r & 3) + 8 * (r >> 2);
-        if (!(vg && o < p.cout)) continue;
-        float* dst = dpos + (long long)o * p.out_plane_stride;
+      for (int g = 0; g < RNP; ++g) {
+        const int py_ = y0 + wave * RNP + g, px_ = x0 + l31;       // position
+        const bool vg = py_ < p.gh && px_ < p.gw;
+        constexpr int SC = MODE == 1 ? 2 : 1;
+        const unsigned vof = (BST && vg) ? (unsigned)(((long long)(4 * khalf) * dps + (long long)(SC * py_) * drs + SC * px_) * 4) : 0xFFFFFFF0u;
+        if constexpr (MODE != 1) {
+          const int pix = vg ? py_ * p.ow + px_ : 0;
+          const float nz = (ACT && p.noise) ? __fmul_rn(nw, p.noise[(long long)(p.noise_batch == 1 ? 0 : b) * p.oh * p.ow + pix]) : 0.f;
+          float* dpos = dst_b + (long long)(vg ? py_ : 0) * p.out_row_stride + (vg ? px_ : 0);
 #pragma unroll
-        for (int py = 0; py < 2; ++py) {
-          if (2 * py_ + py >= p.oh) continue;
-          const float v0 = acc[g][py * 2][r] * dm_m[r], v1 = acc[g][py * 2 + 1][r] * dm_m[r];
-          if (pair) {
-            f32x2_u t;
-            t.x = v0; t.y = v1;
-            *reinterpret_cast<f32x2_u*>(dst + (long long)py * p.out_row_stride) = t;
-          } else {
-            dst[(long long)py * p.out_row_stride] = v0;
+          for (int r = 0; r < 16; ++r) {
+            const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[g][0][r] * dm_m[r];
+            if constexpr (ACT) {
+              v = __fadd_rn(__fadd_rn(v, nz), bias_m[r]);
+              v = (v > 0.f ? v : v * alpha) * ascale;
+            }
+            if constexpr (BST) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_o, vof, so_m + (unsigned)((r & 3) + 8 * (r >> 2)) * dps4, 0);
+            else if (vg && o < p.cout) dpos[(long long)o * p.out_plane_stride] = v;
+          }
+        } else {
+          float* dpos = dst_b + (long long)(vg ? 2 * py_ : 0) * p.out_row_stride + (vg ? 2 * px_ : 0);
+          const bool pair = 2 * px_ + 1 < p.ow;          // position n = w owns the last output column only
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = orow + m * 32 + (r & 3) + 8 * (r >> 2);
+            if constexpr (BST) {
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                u32x2 t;
+                t.x = __float_as_uint(acc[g][py * 2][r] * dm_m[r]);
+                t.y = __float_as_uint(acc[g][py * 2 + 1][r] * dm_m[r]);
+                __builtin_amdgcn_raw_buffer_store_b64(t, rsrc_o, vof, so_m + (unsigned)((r & 3) + 8 * (r >> 2)) * dps4 + (unsigned)py * drs4, 0);
+              }
+            } else {
+              if (!(vg && o < p.cout)) continue;
+              float* dst = dpos + (long long)o * p.out_plane_stride;
+#pragma unroll
+              for (int py = 0; py < 2; ++py) {
+                if (2 * py_ + py >= p.oh) continue;          // position m = h owns the last output row only
+                const float v0 = acc[g][py * 2][r] * dm_m[r], v1 = acc[g][py * 2 + 1][r] * dm_m[r];
+                if (pair) {
+                  f32x2_u t;
+                  t.x = v0; t.y = v1;
+                  *reinterpret_cast<f32x2_u*>(dst + (long long)py * p.out_row_stride) = t;
+                } else {
+                  dst[(long long)py * p.out_row_stride] = v0;
+                }
+              }
+            }
           }
         }
       }
     }
+  };
+  if (bstore) {
+    if (actf) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{});
+  } else {
+    if (actf) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{});
   }
 }
 
