@@ -130,6 +130,57 @@ def test_conv_with_torgb_in_epilogue_vs_c_oracle(cfg):
     np.testing.assert_allclose(rgb3.cpu().numpy(), ref3, **_tol(ref3))
 
 
+@pytest.mark.parametrize('cfg', [
+    # (b, cin, cout, h, w, mode): 32-wide tiles; rows of whole 16-byte groups (the wide patch) and not; several x tiles;
+    # Cout ragged against the channel tile (generic stores) and whole (buffer stores); multi-round launches of the
+    # transposed conv (thin segments shrunk to the main segment's LDS image)
+    (1, 16, 32, 40, 36, 0), (1, 16, 32, 40, 38, 0), (2, 8, 64, 36, 68, 0), (1, 24, 20, 33, 100, 0), (1, 8, 128, 37, 96, 0),
+    (1, 16, 32, 40, 36, 1), (1, 16, 32, 40, 38, 1), (2, 8, 64, 20, 68, 1), (1, 24, 20, 19, 52, 1),
+    (3, 16, 32, 96, 160, 1), (4, 8, 32, 256, 256, 1), (2, 8, 64, 256, 512, 1), (2, 16, 32, 192, 256, 0),
+])
+def test_modconv_wide_patch_and_buffer_store_paths_vs_c_oracle(cfg):
+    """Round 3's staging and store paths of the fp32 kernel (16-byte patch pieces, buffer-store epilogue, bias / demod / style
+    through LDS) against the C oracle, with and without the fused activation; plus their fall-backs: the same tensors at a
+    4-byte-misaligned address (4-byte patch pieces) and into a strided, odd-aligned output must give the SAME BITS."""
+    from op import _native
+    from oracle import c_oracle
+    b, cin, cout, h, w, mode = cfg
+    x = synth.tensor(f'wide/{cfg}/x', (b, cin, h, w))
+    wgt = synth.tensor(f'wide/{cfg}/w', (cout, cin, 3, 3))
+    s = synth.tensor(f'wide/{cfg}/s', (b, cin), shift=1.0, scale=0.5)
+    scale = 1.0 / np.sqrt(cin * 9)
+    ref = c_oracle.modulated_conv2d(x.numpy(), wgt.numpy(), s.numpy(), mode=mode, demodulate=True)
+    d = dev()
+    xd, wd, sd = x.to(d), wgt.to(d), s.to(d)
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale)
+    y = _native.modconv2d(xd, wt, sd, dm, mode)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+    # same input one float further (not 16-byte aligned): the 4-byte staging path
+    flat = torch.empty(xd.numel() + 1, dtype=torch.float32, device=d)
+    xm = flat[1:].view_as(xd)
+    xm.copy_(xd)
+    assert xm.data_ptr() % 16 == 4 and xm.is_contiguous()
+    assert torch.equal(_native.modconv2d(xm, wt, sd, dm, mode), y)
+    # strided output (the aligned-row layout of the upsampling branch: first element at base + 4 bytes)
+    oh, ow = y.shape[2:]
+    buf, p0, ps, rs = _native.aligned_rows_buffer(b, cout, oh, ow, 1, d)
+    buf.fill_(float('nan'))
+    _native.modconv2d(xd, wt, sd, dm, mode, strided_out=(p0, ps, rs))
+    assert torch.equal(buf[:, :, 1:1 + ow].reshape(b, cout, oh, ow), y)
+    assert torch.isnan(buf[:, :, 0]).all() and torch.isnan(buf[:, :, 1 + ow:]).all()
+    if mode == 0:
+        noise = synth.tensor(f'wide/{cfg}/n', (1, 1, h, w))
+        bias = synth.tensor(f'wide/{cfg}/b', (cout,))
+        nw = torch.tensor([0.3])
+        pre = ref + np.float32(0.3) * noise.numpy() + bias.numpy()[None, :, None, None]
+        act = (np.where(pre > 0, pre, pre * np.float32(0.2)) * np.float32(2 ** 0.5)).astype(np.float32)
+        ya = _native.modconv2d(xd, wt, sd, dm, 0, noise=noise.to(d), noise_weight=nw.to(d), bias=bias.to(d), fuse_act=True)
+        np.testing.assert_allclose(ya.cpu().numpy(), act, **_tol(act))
+        assert torch.equal(_native.modconv2d(xm, wt, sd, dm, 0, noise=noise.to(d), noise_weight=nw.to(d), bias=bias.to(d),
+                                             fuse_act=True), ya)
+
+
 def test_rgb_fusable_is_host_logic_and_unsupported_shapes_are_refused():
     from op import _native
     assert _native.modconv2d_rgb_fusable(8, 32, 32, 1024, 1024) and _native.modconv2d_rgb_fusable(8, 64, 64, 512, 512)
