@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void modconv_demod_f32(const float* __restrict
       wsq[j] = q;
     }
   }
-  for (int b = 0; b < batch; ++b) {
+  // PRE (inference): one wave per (output channel, sample) — the grid's y extent covers the batch, so the samples' style
+  // loads are independent waves instead of `batch` dependent round trips inside one wave.  The raw-weight form keeps one
+  // wave per channel (it squares nine taps per weight; repeating that per sample would cost more than it hides).
+  for (int b = blockIdx.y; b < batch; b += gridDim.y) {
     const float* sb = style + (long long)b * cin;
     float acc = 0.f;
     if (cached) {
@@ -1885,7 +1888,7 @@ extern "C" int fmgan_modconv_demod_wsq_f32(const float* wsq, const float* style,
   if (batch < 0 || cout <= 0 || cin <= 0) return FMGAN_EINVAL;
   if (batch == 0) return FMGAN_OK;
   if (!wsq || !style || !demod) return FMGAN_EINVAL;
-  hipLaunchKernelGGL(modconv_demod_f32<true>, dim3((cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, wsq, style, demod,
+  hipLaunchKernelGGL(modconv_demod_f32<true>, dim3((cout + 3) / 4, batch < 64 ? batch : 64), dim3(256), 0, (hipStream_t)stream, wsq, style, demod,
                      batch, cout, cin, 1, scale, eps);
   return fmgan_check_launch();
 }
