@@ -60,6 +60,7 @@ def lib():
     _sig(L.fmgan_modconv_demod_f32, [vp] * 3 + [i] * 4 + [f, f, vp])
     _sig(L.fmgan_modconv_wsq_f32, [vp] * 2 + [i] * 3 + [vp])
     _sig(L.fmgan_modconv_demod_wsq_f32, [vp] * 3 + [i] * 3 + [f, f, vp])
+    _sig(L.fmgan_equal_linear_f32, [vp] * 4 + [i] * 3 + [vp])
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, i, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
@@ -350,6 +351,20 @@ def modconv_demod(weight, style, scale, eps=1e-8, wsq=None):
             check(lib().fmgan_modconv_demod_f32(fp(weight), fp(style), fp(demod), style.shape[0], cout, cin,
                                                 kh * kw, float(scale), float(eps), stream), 'modconv_demod')
     return demod
+
+
+def equal_linear(x, weight, bias=None):
+    """out = x @ weight.T (+ bias): x [B,K] f32, weight [N,K] f32 (already scaled), bias [N] or None -> [B,N]."""
+    require_gpu(x, 'input')
+    x, weight = x.contiguous(), weight.contiguous()
+    b, k = x.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k:
+        raise RuntimeError(f'equal_linear: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}')
+    out = torch.empty((b, n), dtype=torch.float32, device=x.device)
+    with on_device(x) as stream:
+        check(lib().fmgan_equal_linear_f32(fp(x), fp(weight), fp(bias), fp(out), b, n, k, stream), 'equal_linear')
+    return out
 
 
 def modconv_wsq(weight):

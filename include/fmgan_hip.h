@@ -195,6 +195,15 @@ int fmgan_modconv_demod_f32(const float *weight, const float *style, float *demo
                             float scale, float eps, void *stream);
 
 /*
+ * EqualLinear at inference batch sizes (replaces F.linear(input, weight*scale, bias=bias*lr_mul) of
+ * /root/reference/stylegan2.py:146-180 where it is a ModulatedConv2d's modulation, stylegan2.py:226):
+ *   out[b,n] = sum_k x[b,k] * weight[n,k] (+ bias[n])      x [batch,k_in], weight [n_out,k_in] (already scaled), bias [n_out] or NULL
+ * One wave per (n, b), fixed summation order: bit-reproducible and independent of the batch size.
+ */
+int fmgan_equal_linear_f32(const float *x, const float *weight, const float *bias, float *out,
+                           int batch, int n_out, int k_in, void *stream);
+
+/*
  * The same coefficients in two steps, for weights that change rarely (inference, or once per optimiser step):
  *   fmgan_modconv_wsq_f32:        wsq[o,i] = sum_k weight[o,i,k]^2          [cout, cin] f32, cached by the caller
  *   fmgan_modconv_demod_wsq_f32:  demod[b,o] = rsqrt(scale^2 * sum_i wsq[o,i] * style[b,i]^2 + eps)

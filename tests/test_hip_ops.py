@@ -531,3 +531,25 @@ def test_prelu_backward_kernel_vs_float64_autograd(shape):
     np.testing.assert_allclose(gx.detach().cpu().numpy(), x64.grad.numpy(), rtol=1e-6, atol=1e-7)
     gg, = torch.autograd.grad(gx.sum(), m.weight)
     assert torch.isfinite(gg).all()
+
+
+@pytest.mark.parametrize('shape', [(8, 512, 512), (1, 512, 32), (3, 40, 7), (64, 512, 512), (5, 100, 130), (2, 2048, 64)])
+def test_equal_linear_matches_f_linear(shape):
+    """fmgan_equal_linear_f32 (EqualLinear at inference batch sizes, stylegan2.py:146-180 / :226) against float64 F.linear:
+    within fp32 summation error, bit-reproducible, and independent of which other samples share the batch."""
+    from op import _native
+    b, k, n = shape
+    x = synth.tensor(f'lin/{shape}/x', (b, k))
+    w = synth.tensor(f'lin/{shape}/w', (n, k))
+    bias = synth.tensor(f'lin/{shape}/b', (n,))
+    ref = torch.nn.functional.linear(x.double(), w.double(), bias.double()).numpy()
+    xd, wd, bd = x.to(dev()), w.to(dev()), bias.to(dev())
+    y = _native.equal_linear(xd, wd, bd)
+    tol = 4e-6 * float(np.abs(x.numpy()).max() * np.abs(w.numpy()).max()) * k ** 0.5
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=tol, rtol=0)
+    assert torch.equal(_native.equal_linear(xd, wd, bd), y)
+    assert torch.equal(_native.equal_linear(xd[b - 1:], wd, bd), y[b - 1:])
+    y0 = _native.equal_linear(xd, wd, None)
+    np.testing.assert_allclose(y0.cpu().numpy(), ref - bias.numpy()[None].astype(np.float64), atol=tol, rtol=0)
+    with pytest.raises(RuntimeError):
+        _native.equal_linear(xd, wd[:, :-1].contiguous(), None)
