@@ -210,7 +210,9 @@ def test_styled_conv_golden_fused_and_unfused(c, golden):
     y_graph = m(x, w, noise=nz)                          # autograd path: three separate ops
     np.testing.assert_allclose(y_fused.cpu().numpy(), ref, **_tol(ref))
     np.testing.assert_allclose(y_graph.detach().cpu().numpy(), ref, **_tol(ref))
-    torch.testing.assert_close(y_fused, y_graph.detach(), atol=1e-6, rtol=1e-6)
+    # (the two paths share every kernel but the modulation linear: the inference path's matrix-vector kernel and the BLAS
+    # GEMM of the autograd path add in different orders, so the style vector differs in its last bit)
+    torch.testing.assert_close(y_fused, y_graph.detach(), atol=5e-6, rtol=1e-5)
 
 
 @pytest.mark.parametrize('c', cases.TORGB_CASES, ids=lambda c: c['name'])
