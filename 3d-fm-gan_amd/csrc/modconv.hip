@@ -1185,7 +1185,7 @@ int launch_cfg(MCParams& p, hipStream_t s) {
 // FMGAN_MC_CLOCKPTR; the product library has no environment switch and no ablation code path.
 inline char mc_variant(int mode, int cfg) {
 #ifndef FMGAN_EXPERIMENTS
-  static const char defaults[3][3] = {{'C', 'C', 'D'}, {'A', 'B', 'D'}, {'A', 'A', 'A'}};   // comments: see below
+  static const char defaults[3][3] = {{'C', 'C', 'E'}, {'A', 'B', 'D'}, {'A', 'A', 'A'}};   // comments: see below
   return defaults[mode][cfg];
 #else
   // (read per call: the A/B tools sweep variants inside one process)
@@ -1195,14 +1195,15 @@ inline char mc_variant(int mode, int cfg) {
   // (C: 1701 us at 1024^2; 32 x 128 by LDS-DMA 1809, register pipeline 1760-1790, 32 x 512 1873);
   // transposed conv: LDS-DMA (B) for every width.
   // Round 3 (profiles/r03_modconv_block_phases.md, r03_modconv_layers_ab.md), after the wide patch and the buffer-store
-  // epilogue: Cout < 48 plain: 32 x 256 in 4-channel chunks (D: 24 KB of LDS and 96 registers, 5 blocks per CU instead of
-  // 3; 1446 -> 1373 us at 1024^2, with the fused ToRGB 1852 -> 1817); transposed 32-channel tile in a 128-register budget
-  // (D: 4 blocks per CU instead of 3, 8 spilled dwords in the epilogue; 785 -> 757 us at 512^2).
-  const char defaults[3][3] = {{'C', 'C', 'D'}, {'A', 'B', 'D'}, {'A', 'A', 'A'}};
+  // epilogue: Cout < 48 plain: 32 x 256 in 4-channel chunks (24 KB of LDS): E = in a 128-register budget, 4 blocks per
+  // CU instead of 3, no spills (1446 -> 1361 us at 1024^2, with the fused ToRGB 1852 -> 1796-1800); D = in a 96-register
+  // budget, 5 blocks per CU, 55-90 spilled dwords: 1 % behind E (1377 / 1806-1826).  Transposed 32-channel tile in a
+  // 128-register budget (D: 4 blocks per CU instead of 3, 7 spilled dwords in the epilogue; 785 -> 757 us at 512^2).
+  const char defaults[3][3] = {{'C', 'C', 'E'}, {'A', 'B', 'D'}, {'A', 'A', 'A'}};
   char name[32];
   snprintf(name, sizeof(name), "FMGAN_MC_V%d%d", mode, cfg);
   const char* e = getenv(name);
-  return (e && e[0] >= 'A' && e[0] <= 'D') ? e[0] : defaults[mode][cfg];
+  return (e && e[0] >= 'A' && e[0] <= 'E') ? e[0] : defaults[mode][cfg];
 #endif
 }
 
@@ -1259,7 +1260,7 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
     if (cfg < 2 && (small || p.rgb_out)) v = (!p.rgb_out && (long long)p.batch * p.h * p.w >= 1536) ? 'B' : 'A';
     else if (cfg == 2 && small) v = 'B';
   }
-  if (mode == 0 && v == 'D') {
+  if (mode == 0 && (v == 'D' || v == 'E')) {
     const bool small = p.ksplit > 1 || blocks_with(p, 32, 256) < 2LL * FMGAN_NUM_CU;
     if (small) v = 'B';
   }
@@ -1278,6 +1279,7 @@ inline int launch_any(int mode, int cfg, MCParams& p, hipStream_t s) {
         if (v == 'B') st = launch_cfg<0, 1, 1, 1, 4, 4, 8, 1>(p, s);
         else if (v == 'C') st = launch_cfg<0, 1, 2, 1, 4, 3, 8, 1>(p, s);                      // 32 x 256, 3 blocks per CU
         else if (v == 'D') st = launch_cfg<0, 1, 2, 1, 4, 5, 4, 1>(p, s);                      // 32 x 256, 4-channel chunks: 5-6 blocks per CU
+        else if (v == 'E') st = launch_cfg<0, 1, 2, 1, 4, 4, 4, 1>(p, s);                      // the same in a 128-register budget (4 blocks per CU, no spills)
         return st != 1 ? st : launch_cfg<0, 1, 1, 1, 4, 4>(p, s);
     }
   }
