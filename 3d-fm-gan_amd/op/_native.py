@@ -61,6 +61,9 @@ def lib():
     _sig(L.fmgan_modconv_wsq_f32, [vp] * 2 + [i] * 3 + [vp])
     _sig(L.fmgan_modconv_demod_wsq_f32, [vp] * 3 + [i] * 3 + [f, f, vp])
     _sig(L.fmgan_equal_linear_f32, [vp] * 4 + [i] * 3 + [vp])
+    _sig(L.fmgan_wino_weight_f32, [vp, vp, i, i, vp])
+    _sig(L.fmgan_wino_input_f32, [vp] * 3 + [i] * 4 + [vp])
+    _sig(L.fmgan_wino_output_f32, [vp] * 6 + [i] * 6 + [f, f, vp])
     _sig(L.fmgan_modconv_weight_prep_f32, [vp, vp, i, i, i, f, i, vp])
     _sig(L.fmgan_modconv2d_workspace_bytes, [i] * 6, ll)
     _sig(L.fmgan_modconv2d_f32, [vp] * 5 + [i] * 6 + [vp] * 3 + [i, i, f, f, ll, i, vp, ll, vp])
@@ -442,6 +445,46 @@ def modconv_weight_to_bf16(wt):
     with on_device(wt) as stream:
         check(lib().fmgan_modconv_weight_to_bf16(fp(wt), ptr(wtb), cin, cout, taps, stream), 'modconv_weight_to_bf16')
     return wtb
+
+
+def wino_weight(wt):
+    """fp32 MFMA layout wt [cin, 9, cout] (scaled) -> Winograd F(2x2,3x3) weight U [16, cout, cin]."""
+    cin, taps, cout = wt.shape
+    if taps != 9:
+        raise RuntimeError('wino_weight: 3x3 weights only')
+    u = torch.empty((16, cout, cin), dtype=torch.float32, device=wt.device)
+    with on_device(wt) as stream:
+        check(lib().fmgan_wino_weight_f32(fp(wt), fp(u), cin, cout, stream), 'wino_weight')
+    return u
+
+
+def modconv2d_winograd(x, wt, style, demod, noise=None, noise_weight=None, bias=None, fuse_act=False, alpha=0.2,
+                       act_scale=2 ** 0.5, u=None):
+    """Plain 3x3 modulated conv in Winograd F(2x2,3x3) form: input transform (own kernel), 16 batched fp32 GEMMs (torch.bmm ->
+    the BLAS library), output transform + StyledConv epilogue (own kernel).  x [B,cin,H,W] with H, W even; wt as for
+    modconv2d (or u = wino_weight(wt) prepared by the caller)."""
+    require_gpu(x, 'input')
+    x, style = x.contiguous(), style.contiguous()
+    b, cin, h, w = x.shape
+    if (h | w) & 1:
+        raise RuntimeError('modconv2d_winograd: H and W must be even')
+    if u is None:
+        u = wino_weight(wt)
+    cout = u.shape[1]
+    n = b * (h // 2) * (w // 2)
+    v = torch.empty((16, cin, n), dtype=torch.float32, device=x.device)
+    m = torch.empty((16, cout, n), dtype=torch.float32, device=x.device)
+    out = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+    nz = noise.contiguous() if noise is not None else None
+    with on_device(x) as stream:
+        tok = _observer.begin('modconv2d_winograd', (b, cin, cout, h, w, 0))
+        check(lib().fmgan_wino_input_f32(fp(x), fp(style), fp(v), b, cin, h, w, stream), 'wino_input')
+        torch.bmm(u, v, out=m)
+        check(lib().fmgan_wino_output_f32(fp(m), fp(demod), fp(nz), fp(noise_weight), fp(bias), fp(out), b, cout, h, w,
+                                          1 if nz is None else nz.shape[0], int(bool(fuse_act)), float(alpha),
+                                          float(act_scale), stream), 'wino_output')
+        _observer.end(tok)
+    return out
 
 
 def modconv_weight_to_bf16x3(wt):

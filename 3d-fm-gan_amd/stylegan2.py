@@ -296,6 +296,17 @@ class ConstantInput(nn.Module):
         return self.input.repeat(input.shape[0], 1, 1, 1)
 
 
+WINOGRAD = os.environ.get('FMGAN_NO_WINOGRAD', '0') != '1'   # Winograd F(2x2,3x3) form of the wide plain convs (inference)
+
+
+def winograd_pays(batch, cin, cout, h, w):
+    """Plain StyledConv layers served by the Winograd form (op/_native.py: modconv2d_winograd) instead of the direct MFMA kernel.
+    Measured at B = 8 (profiles/r03_winograd.md): 16^2..64^2 x 512 channels 1.6-1.9x, 128^2 x 256 channels 1.23x, 256^2 x 128
+    channels 0.83x (its transforms move 4x the activation through HBM): wide layers of at most 128^2 only, with enough tiles
+    for the 16 GEMMs to fill the chip."""
+    if not WINOGRAD or _native.current_modconv_precision() != 'f32' or (h | w) & 1:
+        return False
+    return cin >= 256 and cout >= 256 and 16 <= h <= 128 and 16 <= w <= 128 and batch * (h // 2) * (w // 2) >= 512
 FUSE_RGB = os.environ.get('FMGAN_NO_RGB_FUSE', '0') != '1'   # ToRGB in the preceding conv's epilogue (inference)
 
 
@@ -361,6 +372,12 @@ class StyledConv(nn.Module):
                                                     rs, conv.blur.kernel, pad0, pad1, pad0, pad1).view(b, c, oh, ow)
                     out = _native.noise_bias_act(out, noise, self.noise.weight, act.bias, act.negative_slope, act.scale)
             del buf
+        elif winograd_pays(b, conv.in_channel, conv.out_channel, h, w):
+            # 16 products per 2x2 output tile instead of 36 (own transform kernels around 16 batched library GEMMs): the
+            # direct kernel is already at 0.84-0.88 of the fp32 matrix peak on these layers
+            out = _native.modconv2d_winograd(input, conv.mfma_weight(), s, demod, noise=noise,
+                                             noise_weight=self.noise.weight, bias=act.bias, fuse_act=True,
+                                             alpha=act.negative_slope, act_scale=act.scale)
         else:
             out = _native.modconv2d(input, conv.mfma_weight(), s, demod, 0, noise=noise,
                                     noise_weight=self.noise.weight, bias=act.bias, fuse_act=True,

@@ -195,6 +195,22 @@ int fmgan_modconv_demod_f32(const float *weight, const float *style, float *demo
                             float scale, float eps, void *stream);
 
 /*
+ * Winograd F(2x2,3x3) form of the plain 3x3 modulated conv (mode 0 of fmgan_modconv2d_f32; /root/reference/stylegan2.py:250-298):
+ * 16 products per 2x2 output tile instead of 36.  Three steps; the middle one is a plain batched GEMM done by the caller
+ * (M[xi] = U[xi] @ V[xi], xi = 0..15).  H and W even; T = (H/2)*(W/2) tiles per sample; fp32; results differ from the direct
+ * kernel by fp32 rounding of re-associated sums.
+ *   fmgan_wino_weight_f32:  wt [cin,9,cout] (fmgan_modconv_weight_prep_f32, kind 0) -> U [16, cout, cin]
+ *   fmgan_wino_input_f32:   x [B,C,H,W], style [B,C] -> V [16, C, B*T]   (column b*T + ty*(W/2) + tx; modulated, zero padded)
+ *   fmgan_wino_output_f32:  M [16, cout, B*T] -> out [B,cout,H,W] contiguous = epilogue(demod * At M A); demod / noise /
+ *                           bias may be NULL; epilogue as fmgan_modconv2d_f32 with fuse_act
+ */
+int fmgan_wino_weight_f32(const float *wt, float *u, int cin, int cout, void *stream);
+int fmgan_wino_input_f32(const float *x, const float *style, float *v, int batch, int c, int h, int w, void *stream);
+int fmgan_wino_output_f32(const float *m, const float *demod, const float *noise, const float *noise_weight,
+                          const float *bias, float *out, int batch, int cout, int h, int w, int noise_batch,
+                          int fuse_act, float alpha, float act_scale, void *stream);
+
+/*
  * EqualLinear at inference batch sizes (replaces F.linear(input, weight*scale, bias=bias*lr_mul) of
  * /root/reference/stylegan2.py:146-180 where it is a ModulatedConv2d's modulation, stylegan2.py:226):
  *   out[b,n] = sum_k x[b,k] * weight[n,k] (+ bias[n])      x [batch,k_in], weight [n_out,k_in] (already scaled), bias [n_out] or NULL

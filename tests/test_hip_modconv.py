@@ -181,6 +181,40 @@ def test_modconv_wide_patch_and_buffer_store_paths_vs_c_oracle(cfg):
                                              fuse_act=True), ya)
 
 
+@pytest.mark.parametrize('cfg', [(2, 16, 32, 8, 8), (1, 24, 40, 34, 36), (3, 8, 16, 2, 6), (2, 64, 64, 32, 32), (1, 128, 64, 64, 48),
+                                 (2, 7, 5, 10, 4)])
+@pytest.mark.parametrize('act', [False, True])
+def test_winograd_form_vs_c_oracle(cfg, act):
+    """fmgan_wino_{weight,input,output}_f32 + 16 batched GEMMs (Winograd F(2x2,3x3) form of the plain modulated conv) against the
+    C oracle at the direct kernel's tolerance, with and without the fused StyledConv epilogue, and against the direct kernel."""
+    from op import _native
+    from oracle import c_oracle
+    b, cin, cout, h, w = cfg
+    x = synth.tensor(f'wino/{cfg}/x', (b, cin, h, w))
+    wgt = synth.tensor(f'wino/{cfg}/w', (cout, cin, 3, 3))
+    s = synth.tensor(f'wino/{cfg}/s', (b, cin), shift=1.0, scale=0.5)
+    scale = 1.0 / np.sqrt(cin * 9)
+    ref = c_oracle.modulated_conv2d(x.numpy(), wgt.numpy(), s.numpy(), mode=0, demodulate=True)
+    d = dev()
+    xd, wd, sd = x.to(d), wgt.to(d), s.to(d)
+    wt = _native.modconv_weight_prep(wd, scale)
+    dm = _native.modconv_demod(wd, sd, scale)
+    kw = {}
+    if act:
+        noise = synth.tensor(f'wino/{cfg}/n', (1, 1, h, w))
+        bias = synth.tensor(f'wino/{cfg}/b', (cout,))
+        pre = ref + np.float32(0.3) * noise.numpy() + bias.numpy()[None, :, None, None]
+        ref = (np.where(pre > 0, pre, pre * np.float32(0.2)) * np.float32(2 ** 0.5)).astype(np.float32)
+        kw = dict(noise=noise.to(d), noise_weight=torch.tensor([0.3], device=d), bias=bias.to(d), fuse_act=True)
+    y = _native.modconv2d_winograd(xd, wt, sd, dm, **kw)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, **_tol(ref))
+    yd = _native.modconv2d(xd, wt, sd, dm, 0, **kw)
+    np.testing.assert_allclose(y.cpu().numpy(), yd.cpu().numpy(), **_tol(ref))
+    assert torch.equal(_native.modconv2d_winograd(xd, wt, sd, dm, **kw), y)          # bit-reproducible
+    with pytest.raises(RuntimeError):
+        _native.modconv2d_winograd(xd[:, :, :-1], wt, sd, dm)                          # odd height
+
+
 def test_rgb_fusable_is_host_logic_and_unsupported_shapes_are_refused():
     from op import _native
     assert _native.modconv2d_rgb_fusable(8, 32, 32, 1024, 1024) and _native.modconv2d_rgb_fusable(8, 64, 64, 512, 512)
