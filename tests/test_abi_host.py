@@ -345,3 +345,24 @@ def test_live_weights_deepcopy_starts_without_table():
     assert lw2 is not lw and lw2.root is G2
     assert lw2._key is None and lw2._table is None and lw2._buffers == [] and not lw2.active
     assert lw._key == ('stale',)
+
+
+def test_winograd_selection_rule_is_host_logic():
+    """stylegan2.winograd_pays: which plain StyledConv layers take the Winograd F(2x2,3x3) form — wide layers of
+    16^2..128^2 with enough tiles, fp32 precision only, even sizes only."""
+    import stylegan2
+    from op import _native
+    assert stylegan2.winograd_pays(8, 512, 512, 64, 64) and stylegan2.winograd_pays(8, 256, 256, 128, 128)
+    assert stylegan2.winograd_pays(8, 512, 512, 16, 16) and stylegan2.winograd_pays(32, 512, 512, 16, 16)
+    assert not stylegan2.winograd_pays(8, 128, 128, 256, 256)       # transforms cost more than the saved MACs
+    assert not stylegan2.winograd_pays(8, 64, 64, 512, 512) and not stylegan2.winograd_pays(8, 512, 512, 8, 8)
+    assert not stylegan2.winograd_pays(1, 512, 512, 16, 16)         # 64 tiles: too few columns for the 16 GEMMs
+    assert not stylegan2.winograd_pays(8, 512, 512, 63, 64) and not stylegan2.winograd_pays(8, 512, 256, 64, 65)
+    with _native.modconv_precision('bf16x3'):
+        assert not stylegan2.winograd_pays(8, 512, 512, 64, 64)
+    old = stylegan2.WINOGRAD
+    try:
+        stylegan2.WINOGRAD = False
+        assert not stylegan2.winograd_pays(8, 512, 512, 64, 64)
+    finally:
+        stylegan2.WINOGRAD = old
